@@ -1,0 +1,80 @@
+/*
+ * tai_sepconv.h -- C ABI of the MI355X-native adaptive separable convolution.
+ *
+ * Drop-in boundary for the reference's only native component.  Each entry point
+ * replaces one symbol of the reference's cffi-exported C shim:
+ *
+ *   tai_sepconv_forward   <- int SeparableConvolution_cuda_forward(THCudaTensor* input, vertical,
+ *                            horizontal, output, int ks)
+ *                            src/separable_convolution/cfile/SeparableConvolution_cuda.h:1-7
+ *                            (body cuda.c:8-25 -> launcher SeparableConvolution_kernel.cu:164-185)
+ *   tai_sepconv_backward  <- int SeparableConvolution_cuda_backward(grad_output, input, vertical,
+ *                            horizontal, grad_input, grad_vertical, grad_horizontal, int ks)
+ *                            src/separable_convolution/cfile/SeparableConvolution_cuda.h:9-18
+ *                            (body cuda.c:28-51 -> launcher SeparableConvolution_kernel.cu:187-242)
+ *
+ * THC tensor handles no longer exist (torch >= 1.0), so tensors cross the boundary as raw device
+ * pointers plus their dimensions.  Conventions kept from the reference:
+ *   - the CALLER owns and pre-allocates every buffer, outputs included; the callee only writes
+ *     (SeparableConvolution.py:36,69-71).  Outputs need not be zeroed: every element is written.
+ *   - all tensors are contiguous fp32 NCHW on the device the stream belongs to;
+ *   - the call is asynchronous on `stream` (the reference used the THC current stream) and does
+ *     no host synchronisation, allocation or copy, so it can be captured into a hipGraph.
+ * Convention changed: the reference returned 1 unconditionally and reported launch failures through
+ * THCudaCheck; these functions return TAI_SEPCONV_OK (0) or a negative TAI_SEPCONV_E* code, and
+ * tai_sepconv_last_error() gives the text.
+ *
+ * Shapes (Hp = H + ks - 1, Wp = W + ks - 1; the reference asserts exactly this relation,
+ * SeparableConvolution.py:27-29):
+ *   input       [B, C, Hp, Wp]   replication-padded source frame
+ *   vertical    [B, ks, H, W]    per-pixel vertical taps
+ *   horizontal  [B, ks, H, W]    per-pixel horizontal taps
+ *   output      [B, C, H, W]     out[b,c,y,x] = sum_fy sum_fx in[b,c,y+fy,x+fx] v[b,fy,y,x] h[b,fx,y,x]
+ *   grad_*      same shapes as the tensor they are the gradient of.
+ */
+#ifndef TAI_SEPCONV_H
+#define TAI_SEPCONV_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAI_SEPCONV_OK 0
+#define TAI_SEPCONV_EINVAL (-1)  /* null pointer, non-positive dimension, index space >= 2^31 */
+#define TAI_SEPCONV_ELAUNCH (-2) /* hipGetLastError() after a launch was not hipSuccess */
+
+/* Forward: replaces SeparableConvolution_cuda_forward (SeparableConvolution_cuda.h:1-7). */
+int tai_sepconv_forward(const float* input, const float* vertical, const float* horizontal,
+                        float* output, int B, int C, int H, int W, int ks, void* hip_stream);
+
+/* Backward (all three gradients, in the reference's V, H, I order):
+ * replaces SeparableConvolution_cuda_backward (SeparableConvolution_cuda.h:9-18).
+ * Any of grad_input / grad_vertical / grad_horizontal may be NULL to skip that gradient. */
+int tai_sepconv_backward(const float* grad_output, const float* input, const float* vertical,
+                         const float* horizontal, float* grad_input, float* grad_vertical,
+                         float* grad_horizontal, int B, int C, int H, int W, int ks,
+                         void* hip_stream);
+
+/* Selects a kernel variant for tai_sepconv_forward (benchmarking / tests):
+ *   0 = automatic (default), 1 = generic one-thread-per-output kernel (any shape),
+ *   2 = LDS-tiled, whole tap set register-resident, 3 = LDS-tiled, taps split over half-waves,
+ *   4 = LDS-tiled, register-resident taps, packed fp32 FMAs (v_pk_fma_f32),
+ *   5 = as 4 with the row loop hand-scheduled in gfx950 assembly (v planes by LDS-DMA), 6 = as 5 with
+ *       the tap loads of half the waves deferred behind a workgroup barrier.
+ * Returns the previous value. */
+int tai_sepconv_set_forward_variant(int variant);
+
+/* Algorithmic HBM bytes of one call: each operand read once, each result written once. */
+long long tai_sepconv_forward_bytes(int B, int C, int H, int W, int ks);
+long long tai_sepconv_backward_bytes(int B, int C, int H, int W, int ks);
+
+/* Text of the last error on the calling thread ("" if none). */
+const char* tai_sepconv_last_error(void);
+
+/* Library / ABI version: major*10000 + minor*100 + patch. */
+int tai_sepconv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAI_SEPCONV_H */

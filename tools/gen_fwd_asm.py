@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Generates video-frame-inpainting_amd/csrc/sepconv_fwd_rowloop.inc: the hand-scheduled gfx950 row loop of
+the forward separable convolution, as one inline-asm block with a fixed register map.
+
+Why hand-scheduled: under the 256-VGPR budget hipcc (ROCm 7.2) either sinks the v prefetch to the end
+of the loop body and waits on it immediately, or serialises every ds_read behind an lgkmcnt(0)
+(profiles/r01_notes.md).  Here every load, wait and FMA has a fixed slot:
+
+  per input row (rolled loop, 51 trips for ks = 51), per lane (4 adjacent output pixels):
+    * 1 LDS-DMA (global_load_lds_dwordx4) of the v plane RING rows ahead into a per-wave LDS ring
+      -- no VGPRs are held by loads in flight; the wave waits with a COUNTED vmcnt(RING-1);
+    * 1 ds_read_b128 of this row's v values from the ring;
+    * 14 window reads (13 ds_read_b128 + 1 ds_read_b64), issued 3 chunks ahead of their use, the
+      last three reaching into the next row, each consumed behind a counted lgkmcnt;
+    * 100 v_pk_fma_f32 + 4 v_fmac_f32 (row sums) + 4 v_pk_fma_f32 (fold with v).
+
+Register map (VGPR):
+    v[51p + t]            horizontal tap t of pixel p (p = 0..3, t = 0..50)          v0   .. v203
+    v[204+2p : 205+2p]    ACC_p: (even-slot, odd-slot) partial row sums of pixel p     v204 .. v211
+    v[212+2p : 213+2p]    O_p:   packed output accumulators                            v212 .. v219
+    v[220+4j : 223+4j]    window buffer j (j = chunk % 4)                               v220 .. v235
+    v[236:239]            v values of the row                                           v236 .. v239
+    v240 row window LDS address, v241 ring LDS address (slot 0), v242 global byte offset, v243 temp
+Tap pairing (see sepconv_forward_packed): even pixels pair taps (2i, 2i+1), odd pixels (2i-1, 2i);
+both multiply the aligned window pair W2[m] = (w[2m], w[2m+1]) with m = i + (p >> 1).
+"""
+import os
+
+KS = 51
+PITCH_BYTES = 180 * 4
+RING = 7                 # v rows in flight
+SLOTS = RING + 1         # ring slots (power of two)
+LOOKAHEAD = 3            # window chunks in flight ahead of the one being consumed
+NCHUNK = 14              # 13 x b128 + 1 x b64 = 27 window pairs
+NW2 = 27
+
+A = lambda p, t: 51 * p + t
+ACC = lambda p: 204 + 2 * p
+O = lambda p: 212 + 2 * p
+BUF = lambda k: 220 + 4 * (k % 4)   # k = running chunk number (14 per row: the rotation shifts by 2 per row)
+VV = 236
+V_ROW, V_RING, V_GOFF, V_TMP = 240, 241, 242, 243
+
+# scalar registers (all named explicitly and listed as clobbers, except the inputs)
+S_VPTR_IN = 's[60:61]'   # input: &v[b, 0, 0, 0]
+S_PLANE = 's62'          # input: H*W*4
+S_RINGM0 = 's63'         # input: LDS byte offset of this wave's ring (slot 0)
+S_PTR_LO, S_PTR_HI = 's64', 's65'   # running DMA source pointer
+S_ROW = 's66'            # row counter fy
+S_SLOT_RD = 's67'        # byte offset of the slot read this row   = (fy % SLOTS) * 1024
+S_SLOT_WR = 's68'        # byte offset of the slot the DMA fills    = ((fy + RING) % SLOTS) * 1024
+S_T0, S_T1 = 's69', 's70'
+
+
+def pair(r):
+    return 'v[%d:%d]' % (r, r + 1)
+
+
+def emit_chunk_read(lines, k, row_off, base=0):
+    """window chunk k of the row at byte offset row_off from v240; base = running number of that row's chunk 0."""
+    off = row_off + 16 * k
+    b = BUF(base + k)
+    if k == NCHUNK - 1:
+        lines.append('ds_read_b64 v[%d:%d], v%d offset:%d' % (b, b + 1, V_ROW, off))
+    else:
+        lines.append('ds_read_b128 v[%d:%d], v%d offset:%d' % (b, b + 3, V_ROW, off))
+
+
+def emit_chunk_fmas(lines, k, first_done, base=0):
+    """FMAs that consume window pairs m = 2k, 2k+1 held in buffer k."""
+    ops = []
+    for hh in range(2):
+        m = 2 * k + hh
+        if m >= NW2:
+            continue
+        w = BUF(base + k) + 2 * hh
+        for p in range(4):
+            i = m - (p >> 1)
+            if i < 0 or i > 25:
+                continue
+            if p % 2 == 0:
+                if i <= 24:
+                    ops.append(('pk', p, A(p, 2 * i), w))
+                else:
+                    ops.append(('lo', p, A(p, 50), w))       # tap 50 alone: ACC.lo += h50 * W.lo
+            else:
+                if i == 0:
+                    ops.append(('hi', p, A(p, 0), w))        # tap 0 alone: ACC.hi += h0 * W.hi
+                else:
+                    ops.append(('pk', p, A(p, 2 * i - 1), w))
+    # a pixel's first instruction of the row must be the packed one (it initialises both halves)
+    ops.sort(key=lambda o: 0 if (o[0] == 'pk' or o[1] in first_done) else 1)
+    for kind, p, a, w in ops:
+        if kind == 'pk':
+            if p in first_done:
+                lines.append('v_pk_fma_f32 %s, %s, %s, %s' % (pair(ACC(p)), pair(a), pair(w), pair(ACC(p))))
+            else:
+                lines.append('v_pk_mul_f32 %s, %s, %s' % (pair(ACC(p)), pair(a), pair(w)))
+                first_done.add(p)
+        elif kind == 'lo':
+            assert p in first_done
+            lines.append('v_fmac_f32 v%d, v%d, v%d' % (ACC(p), a, w))
+        else:
+            if p in first_done:
+                lines.append('v_fmac_f32 v%d, v%d, v%d' % (ACC(p) + 1, a, w + 1))
+            else:   # pixel 3: its lone tap 0 comes one chunk before its first pair
+                lines.append('v_mul_f32 v%d, v%d, v%d' % (ACC(p) + 1, a, w + 1))
+                lines.append('v_mov_b32 v%d, 0' % ACC(p))
+                first_done.add(p)
+
+
+def emit_row(L, phase):
+    base = NCHUNK * phase            # running chunk number of this row's chunk 0
+    L.append('s_waitcnt vmcnt(%d)' % (RING - 1))
+    L.append('v_add_u32 v%d, %s, v%d' % (V_TMP, S_SLOT_RD, V_RING))
+    L.append('ds_read_b128 v[%d:%d], v%d' % (VV, VV + 3, V_TMP))
+    # DMA of row fy + RING (source pointer stops advancing at the last row: the tail re-fetches row ks-1)
+    L.append('s_add_u32 %s, %s, %s' % (S_T0, S_RINGM0, S_SLOT_WR))
+    L.append('s_mov_b32 m0, %s' % S_T0)
+    L.append('s_nop 0')
+    L.append('global_load_lds_dwordx4 v%d, s[64:65]' % V_GOFF)
+    L.append('s_cmp_lt_u32 %s, %d' % (S_ROW, KS - 1 - RING))
+    L.append('s_cselect_b32 %s, %s, 0' % (S_T1, S_PLANE))
+    L.append('s_add_u32 %s, %s, %s' % (S_PTR_LO, S_PTR_LO, S_T1))
+    L.append('s_addc_u32 %s, %s, 0' % (S_PTR_HI, S_PTR_HI))
+    L.append('s_add_u32 %s, %s, 1024' % (S_SLOT_RD, S_SLOT_RD))
+    L.append('s_and_b32 %s, %s, %d' % (S_SLOT_RD, S_SLOT_RD, SLOTS * 1024 - 1))
+    L.append('s_add_u32 %s, %s, 1024' % (S_SLOT_WR, S_SLOT_WR))
+    L.append('s_and_b32 %s, %s, %d' % (S_SLOT_WR, S_SLOT_WR, SLOTS * 1024 - 1))
+    first_done = set()
+    for k in range(NCHUNK):
+        nk = k + LOOKAHEAD
+        if nk < NCHUNK:
+            emit_chunk_read(L, nk, 0, base)
+        else:
+            emit_chunk_read(L, nk - NCHUNK, PITCH_BYTES, base + NCHUNK)
+        # outstanding LDS ops after this issue, oldest first: chunk k, k+1, k+2, (v row if k < 3), chunk k+3
+        L.append('s_waitcnt lgkmcnt(%d)' % (LOOKAHEAD + (1 if k < LOOKAHEAD else 0)))
+        emit_chunk_fmas(L, k, first_done, base)
+    # fold with v:  O_p += (v_p, v_p) * ACC_p
+    L.append('v_pk_fma_f32 %s, %s, %s, %s op_sel_hi:[0,1,1]' % (pair(O(0)), pair(VV), pair(ACC(0)), pair(O(0))))
+    L.append('v_pk_fma_f32 %s, %s, %s, %s op_sel:[1,0,0] op_sel_hi:[1,1,1]' % (pair(O(1)), pair(VV), pair(ACC(1)), pair(O(1))))
+    L.append('v_pk_fma_f32 %s, %s, %s, %s op_sel_hi:[0,1,1]' % (pair(O(2)), pair(VV + 2), pair(ACC(2)), pair(O(2))))
+    L.append('v_pk_fma_f32 %s, %s, %s, %s op_sel:[1,0,0] op_sel_hi:[1,1,1]' % (pair(O(3)), pair(VV + 2), pair(ACC(3)), pair(O(3))))
+    L.append('v_add_u32 v%d, %d, v%d' % (V_ROW, PITCH_BYTES, V_ROW))
+    L.append('s_add_u32 %s, %s, 1' % (S_ROW, S_ROW))
+
+
+def gen():
+    L = []
+    # ---------------- prologue: O = 0, start RING DMAs, start the first LOOKAHEAD window reads
+    for p in range(4):
+        L.append('v_mov_b32 v%d, 0' % O(p))
+        L.append('v_mov_b32 v%d, 0' % (O(p) + 1))
+    L.append('s_mov_b32 %s, s60' % S_PTR_LO)
+    L.append('s_mov_b32 %s, s61' % S_PTR_HI)
+    for r in range(RING):
+        L.append('s_add_u32 %s, %s, %d' % (S_T0, S_RINGM0, r * 1024))
+        L.append('s_mov_b32 m0, %s' % S_T0)
+        L.append('s_nop 0')
+        L.append('global_load_lds_dwordx4 v%d, s[64:65]' % V_GOFF)
+        L.append('s_add_u32 %s, %s, %s' % (S_PTR_LO, S_PTR_LO, S_PLANE))
+        L.append('s_addc_u32 %s, %s, 0' % (S_PTR_HI, S_PTR_HI))
+    # s[64:65] now points at row RING
+    L.append('s_mov_b32 %s, 0' % S_ROW)
+    L.append('s_mov_b32 %s, 0' % S_SLOT_RD)
+    L.append('s_mov_b32 %s, %d' % (S_SLOT_WR, RING * 1024))
+    for k in range(LOOKAHEAD):
+        emit_chunk_read(L, k, 0)
+    L.append('.p2align 6')   # (labels are local numeric ones so the block can be instantiated twice)
+    L.append('1:')
+    # 14 chunks per row over 4 buffers: the rotation shifts by 2 per row, so the loop body is TWO rows
+    # (phase 0 and phase 1) and the odd 51st row is emitted once more behind the loop.
+    emit_row(L, 0)
+    emit_row(L, 1)
+    L.append('s_cmp_lt_u32 %s, %d' % (S_ROW, KS - 1))
+    L.append('s_cbranch_scc1 1b')
+    emit_row(L, 0)
+    # ---------------- drain: the three window reads issued for the (non-existent) next row, the DMA tail
+    L.append('s_waitcnt vmcnt(0) lgkmcnt(0)')
+    return L
+
+
+def main():
+    lines = gen()
+    n_pk = sum(1 for l in lines if l.startswith('v_pk_'))
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(here, '..', 'video-frame-inpainting_amd', 'csrc', 'sepconv_fwd_rowloop.inc')
+    with open(out, 'w') as f:
+        f.write('// GENERATED by tools/gen_fwd_asm.py -- do not edit.  Register map and schedule: see the generator.\n')
+        f.write('// ks=%d ring=%d slots=%d lookahead=%d; %d instructions, %d packed.\n' % (KS, RING, SLOTS, LOOKAHEAD, len(lines), n_pk))
+        f.write('#define TAI_FWD_ROWLOOP_RING_SLOTS %d\n' % SLOTS)
+        f.write('#define TAI_FWD_ROWLOOP_ASM \\\n')
+        for l in lines:
+            f.write('    "%s\\n" \\\n' % l)
+        f.write('    ""\n')
+        clob = ['v%d' % r for r in list(range(204, 212)) + list(range(220, 240)) + [243]]
+        clob += ['s%d' % r for r in range(64, 71)] + ['scc', 'memory']   # m0 is written too; hipcc reloads it before each of its own uses
+        f.write('#define TAI_FWD_ROWLOOP_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob))
+    print('wrote %s: %d lines' % (out, len(lines)))
+
+
+if __name__ == '__main__':
+    main()

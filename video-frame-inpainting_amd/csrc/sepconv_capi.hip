@@ -1,0 +1,247 @@
+// C ABI of the MI355X-native adaptive separable convolution (see include/tai_sepconv.h).
+//
+// Replaces the reference's cffi-exported shim SeparableConvolution_cuda_forward / _backward
+// (src/separable_convolution/cfile/SeparableConvolution_cuda.c:8-25, :28-51) and its launchers
+// (SeparableConvolution_kernel.cu:164-185, :187-242).  gfx950 only; no host synchronisation,
+// allocation or copy on any path, so every call can be captured into a hipGraph.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "tai_sepconv.h"
+
+#include "sepconv_fwd.hip.inc"
+#include "sepconv_bwd.hip.inc"
+
+namespace {
+
+thread_local char g_err[256] = "";
+int g_fwd_variant = 0;
+
+int fail(int code, const char* fmt, const char* what) {
+    std::snprintf(g_err, sizeof(g_err), fmt, what);
+    return code;
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        std::snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return TAI_SEPCONV_ELAUNCH;
+    }
+    return TAI_SEPCONV_OK;
+}
+
+bool dims_ok(int B, int C, int H, int W, int ks) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || ks <= 0) return false;
+    const long long lim = 0x7fffffffLL;
+    const long long Hp = H + ks - 1, Wp = W + ks - 1;
+    return (long long)B * C * Hp * Wp < lim && (long long)B * ks * H * W < lim;
+}
+
+template <typename KernelT>
+int allow_lds(KernelT kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return TAI_SEPCONV_OK;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", bytes, hipGetErrorString(e));
+        return TAI_SEPCONV_ELAUNCH;
+    }
+    return TAI_SEPCONV_OK;
+}
+
+template <int KS, int NC, int SPLIT>
+int launch_fwd_tiled(const float* in, const float* v, const float* h, float* out, int B, int C, int c0,
+                     int H, int W, hipStream_t s) {
+    using K = fwd::Cfg<KS, SPLIT>;
+    const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W;
+    const int tiles_y = (H + K::TILE_H - 1) / K::TILE_H;
+    const size_t lds = K::lds_bytes(NC);
+    auto kern = fwd::sepconv_forward_tiled<KS, NC, SPLIT>;
+    if (int rc = allow_lds(kern, lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(K::THREADS), lds, s, in, v, h, out, C, c0,
+                       H, W, tiles_x, tiles_y);
+    return check_launch("sepconv_forward_tiled");
+}
+
+template <int KS, int NC>
+int launch_fwd_packed(const float* in, const float* v, const float* h, float* out, int B, int C, int c0,
+                      int H, int W, hipStream_t s) {
+    using K = fwd::Cfg<KS, 1>;
+    const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W;
+    const int tiles_y = (H + K::TILE_H - 1) / K::TILE_H;
+    const size_t lds = K::lds_bytes(NC);
+    auto kern = fwd::sepconv_forward_packed<KS, NC>;
+    if (int rc = allow_lds(kern, lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(K::THREADS), lds, s, in, v, h, out, C, c0,
+                       H, W, tiles_x, tiles_y);
+    return check_launch("sepconv_forward_packed");
+}
+
+template <bool STAGGER, int DBG = 0>
+int fwd_asm_all_channels(const float* in, const float* v, const float* h, float* out, int B, int C, int H,
+                         int W, hipStream_t s) {
+    using K = fwd::Cfg<51, 1>;
+    const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W;
+    const int tiles_y = (H + K::TILE_H - 1) / K::TILE_H;
+    const size_t lds = ((K::lds_bytes(1) + 1023) & ~(size_t)1023) + 4 * TAI_FWD_ROWLOOP_RING_SLOTS * 1024;
+    auto kern = fwd::sepconv_forward_asm<STAGGER, DBG>;
+    if (int rc = allow_lds(kern, lds)) return rc;
+    for (int c0 = 0; c0 < C; ++c0) {
+        hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(K::THREADS), lds, s, in, v, h, out, C, c0,
+                           H, W, tiles_x, tiles_y);
+        if (int rc = check_launch("sepconv_forward_asm")) return rc;
+    }
+    return TAI_SEPCONV_OK;
+}
+
+template <int KS>
+int fwd_packed_all_channels(const float* in, const float* v, const float* h, float* out, int B, int C,
+                            int H, int W, hipStream_t s) {
+    int c0 = 0;
+    for (; c0 + 3 <= C; c0 += 3)
+        if (int rc = launch_fwd_packed<KS, 3>(in, v, h, out, B, C, c0, H, W, s)) return rc;
+    for (; c0 < C; ++c0)
+        if (int rc = launch_fwd_packed<KS, 1>(in, v, h, out, B, C, c0, H, W, s)) return rc;
+    return TAI_SEPCONV_OK;
+}
+
+template <int KS, int SPLIT>
+int fwd_tiled_all_channels(const float* in, const float* v, const float* h, float* out, int B, int C,
+                           int H, int W, hipStream_t s) {
+    int c0 = 0;
+    for (; c0 + 3 <= C; c0 += 3)
+        if (int rc = launch_fwd_tiled<KS, 3, SPLIT>(in, v, h, out, B, C, c0, H, W, s)) return rc;
+    for (; c0 < C; ++c0)
+        if (int rc = launch_fwd_tiled<KS, 1, SPLIT>(in, v, h, out, B, C, c0, H, W, s)) return rc;
+    return TAI_SEPCONV_OK;
+}
+
+template <int KS, int NC>
+int launch_grad_vh_tiled(const float* gO, const float* in, const float* v, const float* h, float* gV,
+                         float* gH, int B, int H, int W, hipStream_t s) {
+    using K = fwd::Cfg<KS, 1>;
+    const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W;
+    const int tiles_y = (H + K::TILE_H - 1) / K::TILE_H;
+    const size_t lds = K::lds_bytes(NC);
+    const dim3 grid(B * tiles_x * tiles_y), block(K::THREADS);
+    if (gV) {
+        auto kern = bwd::sepconv_grad_v_tiled<KS, NC>;
+        if (int rc = allow_lds(kern, lds)) return rc;
+        hipLaunchKernelGGL(kern, grid, block, lds, s, gO, in, h, gV, H, W, tiles_x, tiles_y);
+        if (int rc = check_launch("sepconv_grad_v_tiled")) return rc;
+    }
+    if (gH) {
+        auto kern = bwd::sepconv_grad_h_tiled<KS, NC>;
+        if (int rc = allow_lds(kern, lds)) return rc;
+        hipLaunchKernelGGL(kern, grid, block, lds, s, gO, in, v, gH, H, W, tiles_x, tiles_y);
+        if (int rc = check_launch("sepconv_grad_h_tiled")) return rc;
+    }
+    return TAI_SEPCONV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tai_sepconv_version(void) { return 100; }
+
+const char* tai_sepconv_last_error(void) { return g_err; }
+
+int tai_sepconv_set_forward_variant(int variant) {
+    const int prev = g_fwd_variant;
+    g_fwd_variant = variant;
+    return prev;
+}
+
+long long tai_sepconv_forward_bytes(int B, int C, int H, int W, int ks) {
+    const long long Hp = H + ks - 1, Wp = W + ks - 1;
+    return 4LL * ((long long)B * C * Hp * Wp + 2LL * B * ks * H * W + (long long)B * C * H * W);
+}
+
+long long tai_sepconv_backward_bytes(int B, int C, int H, int W, int ks) {
+    const long long Hp = H + ks - 1, Wp = W + ks - 1;
+    return 4LL * ((long long)B * C * H * W + 2LL * B * C * Hp * Wp + 4LL * B * ks * H * W);
+}
+
+int tai_sepconv_forward(const float* input, const float* vertical, const float* horizontal,
+                        float* output, int B, int C, int H, int W, int ks, void* hip_stream) {
+    g_err[0] = 0;
+    if (!input || !vertical || !horizontal || !output) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (!dims_ok(B, C, H, W, ks)) return fail(TAI_SEPCONV_EINVAL, "%s", "bad dimensions");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+
+    int variant = g_fwd_variant;
+    const bool tileable = (ks == 51) && (W % 4 == 0);
+    // default: hand-scheduled packed kernel for single-channel frames, half-wave tap split for RGB
+    if (variant == 0) variant = !tileable ? 1 : (C == 1 ? 5 : 3);
+    if (variant != 1 && !tileable)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "tiled forward variants need ks == 51 and W % 4 == 0");
+    switch (variant) {
+        case 1: {
+            const int n = B * C * H * W;
+            hipLaunchKernelGGL(fwd::sepconv_forward_generic, dim3((n + 255) / 256), dim3(256), 0, s, input,
+                               vertical, horizontal, output, n, C, H, W, ks);
+            return check_launch("sepconv_forward_generic");
+        }
+        case 2: return fwd_tiled_all_channels<51, 1>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 3: return fwd_tiled_all_channels<51, 2>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 4: return fwd_packed_all_channels<51>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 5: return fwd_asm_all_channels<false>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 6: return fwd_asm_all_channels<true>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 101: return fwd_asm_all_channels<false, 1>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 102: return fwd_asm_all_channels<false, 2>(input, vertical, horizontal, output, B, C, H, W, s);
+        default: return fail(TAI_SEPCONV_EINVAL, "%s", "unknown forward variant");
+    }
+}
+
+int tai_sepconv_backward(const float* grad_output, const float* input, const float* vertical,
+                         const float* horizontal, float* grad_input, float* grad_vertical,
+                         float* grad_horizontal, int B, int C, int H, int W, int ks, void* hip_stream) {
+    g_err[0] = 0;
+    if (!grad_output || !input || !vertical || !horizontal) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (!dims_ok(B, C, H, W, ks)) return fail(TAI_SEPCONV_EINVAL, "%s", "bad dimensions");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+
+    // gV then gH then gI: the reference's launch order (SeparableConvolution_kernel.cu:201-239).
+    const bool tileable = (ks == 51) && (W % 4 == 0) && (C == 1 || C == 3);
+    if (tileable) {
+        const int rc = (C == 1) ? launch_grad_vh_tiled<51, 1>(grad_output, input, vertical, horizontal,
+                                                                grad_vertical, grad_horizontal, B, H, W, s)
+                                : launch_grad_vh_tiled<51, 3>(grad_output, input, vertical, horizontal,
+                                                                grad_vertical, grad_horizontal, B, H, W, s);
+        if (rc) return rc;
+    } else {
+        const int n = B * ks * H * W;
+        if (grad_vertical) {
+            hipLaunchKernelGGL(bwd::sepconv_grad_v_generic, dim3((n + 255) / 256), dim3(256), 0, s,
+                               grad_output, input, horizontal, grad_vertical, n, C, H, W, ks);
+            if (int rc = check_launch("sepconv_grad_v_generic")) return rc;
+        }
+        if (grad_horizontal) {
+            hipLaunchKernelGGL(bwd::sepconv_grad_h_generic, dim3((n + 255) / 256), dim3(256), 0, s,
+                               grad_output, input, vertical, grad_horizontal, n, C, H, W, ks);
+            if (int rc = check_launch("sepconv_grad_h_generic")) return rc;
+        }
+    }
+    if (grad_input) {
+        const int n = B * (H + ks - 1) * (W + ks - 1);
+        const dim3 grid((n + 255) / 256), block(256);
+        int c0 = 0;
+        for (; c0 + 3 <= C; c0 += 3) {
+            hipLaunchKernelGGL(bwd::sepconv_grad_i_gather<3>, grid, block, 0, s, grad_output, vertical,
+                               horizontal, grad_input, n, C, c0, H, W, ks);
+            if (int rc = check_launch("sepconv_grad_i_gather<3>")) return rc;
+        }
+        for (; c0 < C; ++c0) {
+            hipLaunchKernelGGL(bwd::sepconv_grad_i_gather<1>, grid, block, 0, s, grad_output, vertical,
+                               horizontal, grad_input, n, C, c0, H, W, ks);
+            if (int rc = check_launch("sepconv_grad_i_gather<1>")) return rc;
+        }
+    }
+    return TAI_SEPCONV_OK;
+}
+
+}  // extern "C"
