@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the bi-TAI hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Metric (BASELINE.json): inpainted frames/sec at 128x128, K=F=5, T=5.  Workload = configs[1]: TAI_gray inference, batch
+32 clips per GPU, hipGraph-replayed forward, fp32 (the reference's arithmetic type; no reduced precision anywhere),
+seeded synthetic clips and seeded xavier weights (no network for datasets / checkpoints).  A step is one forward of the
+whole model over one batch; N > 1 shards clips over ranks with no data-path collective (weak scaling); the timed region
+is bracketed by barrier + synchronize and the MAX over ranks is reported.  Inputs are resident in HBM before timing.
+
+The JSON line also carries
+  roofline      the separable-convolution forward kernel at the workload's shape [32,1,128,128]: algorithmic HBM bytes
+                (6,876,944 B per sample) / mean launch duration from HIP events on the launch stream,
+                against the 8 TB/s HBM3E peak; `traffic` is the PMC-measured HBM bytes per launch from the committed
+                rocprofv3 summary (profiles/), or null;
+  cpu_baseline  the CPU oracle (oracle/: PyTorch-CPU convs + the C restatement of the sepconv loops) timed on this
+                host's cores on a bounded sample of the same workload (rank 0, N = 1 only) -- a reported baseline, and
+                the parity check of the GPU output against it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import video_frame_inpainting_amd as vfi                                    # noqa: E402
+from video_frame_inpainting_amd import _native, metrics, parallel, synthetic  # noqa: E402
+from video_frame_inpainting_amd import separable_convolution as sc          # noqa: E402
+from video_frame_inpainting_amd.graph import GraphedForward                 # noqa: E402
+
+K_, T_, F_, H_, W_, C_ = 5, 5, 5, 128, 128, 1
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def sepconv_roofline(device, B, iters=200, warmup=20):
+    ks = 51
+    g = torch.Generator().manual_seed(7)
+    inp = (torch.rand(B, C_, H_ + ks - 1, W_ + ks - 1, generator=g) * 2 - 1).to(device)
+    v = (torch.randn(B, ks, H_, W_, generator=g) * 0.1).to(device)
+    h = (torch.randn(B, ks, H_, W_, generator=g) * 0.1).to(device)
+    f = vfi.SeparableConvolution.apply
+    with torch.no_grad():
+        for _ in range(warmup):
+            f(inp, v, h, ks)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            f(inp, v, h, ks)
+        e1.record()
+        e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    nbytes = sc.forward_bytes(B, C_, H_, W_, ks)
+    achieved = nbytes / us / 1e3          # GB/s
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'sepconv_fwd_pmc.json')
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'kernel': 'sepconv_forward',
+            'shape': [B, C_, H_, W_], 'us_per_launch': round(us, 2), 'algorithmic_bytes': nbytes}
+
+
+def cpu_baseline_and_parity(model, device, n_clips=2):
+    """Oracle forward on the host cores for a bounded sample (n_clips clips of the workload), and GPU-vs-oracle parity."""
+    from oracle import sepconv_oracle, tai_oracle
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    sepconv_oracle.set_num_threads(cores)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    clips = synthetic.make_clips(n_clips, K_ + T_ + F_, C_, H_, W_, synthetic.SEEDS['cfg1'])
+    P, GT, Fo = (torch.from_numpy(x) for x in synthetic.split_clip(clips, K_, T_, F_))
+    with torch.no_grad():
+        tai_oracle.tai_forward(sd, C_, 5, 51, T_, P[:1], Fo[:1])          # warm-up (thread pools, allocator)
+        t0 = time.time()
+        ref = tai_oracle.tai_forward(sd, C_, 5, 51, T_, P, Fo)
+        dt = time.time() - t0
+        out = model(T_, P.to(device), Fo.to(device))
+    diff = (out['pred'].cpu() - ref['pred']).abs()
+    p_gpu, s_gpu, _ = metrics.compute_errors(out['pred'].cpu().numpy(), GT.numpy())
+    p_cpu, s_cpu, _ = metrics.compute_errors(ref['pred'].numpy(), GT.numpy())
+    mse = float(((out['pred'].cpu() - ref['pred']) ** 2).mean())
+    try:
+        cpu_model = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
+    except Exception:
+        cpu_model = 'unknown'
+    base = {'value': round(n_clips * T_ / dt, 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': 'TAI_gray full width, %d clips of 128x128 K=F=5 T=5, 1 warm-up + 1 timed forward of the CPU oracle '
+                      '(torch CPU convs + C/OpenMP sepconv), %.1f s' % (n_clips, dt),
+            'cpu_model': cpu_model, 'torch_threads': torch.get_num_threads()}
+    parity = {'max_abs_pred': float(diff.max()), 'rms_pred': float(np.sqrt(mse)),
+              'psnr_gpu_vs_cpu_pred_db': float(10 * np.log10(4.0 / mse)) if mse > 0 else float('inf'),
+              'psnr_vs_gt_gpu_db': float(p_gpu.mean()), 'psnr_vs_gt_cpu_db': float(p_cpu.mean()),
+              'max_abs_psnr_delta_db': float(np.max(np.abs(p_gpu - p_cpu))),
+              'max_abs_ssim_delta': float(np.max(np.abs(s_gpu - s_cpu)))}
+    return base, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='clips per GPU (configs[1]: 32)')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the hipGraph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank, world, local_rank = parallel.init_from_env()
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    _native.lib()                                   # fail loudly if the HIP library is missing
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    torch.backends.cudnn.benchmark = True           # MIOpen picks its fastest fp32 algorithm during warm-up
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+
+    torch.manual_seed(0)
+    model = vfi.create_model('TAI_gray')
+    model.apply(vfi.util.weights_init)
+    model.to(device).eval()
+    B = args.batch
+    clips = synthetic.make_clips(B, K_ + T_ + F_, C_, H_, W_, synthetic.SEEDS['cfg2'] + rank)
+    P, _, Fo = (torch.from_numpy(x).to(device) for x in synthetic.split_clip(clips, K_, T_, F_))
+
+    if args.no_graph:
+        def step():
+            with torch.no_grad():
+                return model(T_, P, Fo)
+    else:
+        graphed = GraphedForward(model, T_, P, Fo, warmup=2)
+        step = lambda: graphed()
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    line = {
+        'metric': 'inpainted frames/sec (128x128, K=F=5, T=5)',
+        'value': round(world * B * T_ * args.steps / dt, 2),
+        'unit': 'frames/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: bi-TAI (TAI_gray) 128x128 grayscale K=F=5 T=5 inference, batch 32 per GPU, '
+                               'sepconv HIP kernels + %s' % ('eager launches' if args.no_graph else 'hipGraph replay'),
+                   'clips_per_gpu': B, 'global_clips': world * B, 'parallelism': 'clip-sharded x%d, no collective' % world,
+                   'weights': 'seeded xavier-normal init (torch.manual_seed(0))'},
+    }
+    if rank == 0:
+        line['roofline'] = sepconv_roofline(device, B)
+        if world == 1 and not args.no_cpu_baseline:
+            base, parity = cpu_baseline_and_parity(model, device)
+            line['cpu_baseline'] = base
+            line['parity'] = parity
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

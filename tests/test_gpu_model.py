@@ -1,0 +1,134 @@
+"""bi-TAI on the GPU: the product model (HIP sepconv + MIOpen convs) against the golden whole-model runs of the
+reference, against the CPU oracle on a synthetic clip (output and PSNR/SSIM parity), hipGraph replay, and one
+training step of the TAI training environment."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import video_frame_inpainting_amd as vfi
+from video_frame_inpainting_amd import metrics, synthetic
+from video_frame_inpainting_amd.environments import TAITrainingEnvironment, create_eval_environment
+from video_frame_inpainting_amd.graph import GraphedForward
+from oracle import tai_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+KEYS = ('pred', 'pred_forward', 'pred_backward', 'interp_net_outputs_1', 'interp_net_outputs_2')
+
+
+@pytest.fixture(autouse=True)
+def _fp32_convs():
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize('tag', ['gray', 'color'])
+def test_matches_reference_golden_run(golden_dir, tag):
+    z = _load(golden_dir, 'tai_%s.npz' % tag)
+    sd = {k[2:]: torch.from_numpy(v) for k, v in z.items() if k.startswith('w/')}
+    m = vfi.TAIFillInModel(4, int(z['c_dim'][0]), 3, int(z['ks'][0]), num_block=int(z['num_block'][0]), kf_dim=2)
+    m.load_state_dict(sd)
+    m.to(DEV).eval()
+    with torch.no_grad():
+        out = m(int(z['T'][0]), torch.from_numpy(z['P']).to(DEV), torch.from_numpy(z['F']).to(DEV))
+    for k in KEYS:                      # full model, tanh-bounded outputs: max-abs 2e-4
+        np.testing.assert_allclose(out[k].cpu().numpy(), z['out/' + k], rtol=0, atol=2e-4, err_msg=k)
+
+
+def test_cfg1_shape_matches_cpu_oracle_and_psnr_parity():
+    # BASELINE config 0 geometry (TAI_gray, 128x128 gray, K=F=5, T=5, B=1) at reduced width so the CPU side takes seconds
+    torch.manual_seed(0)
+    m = vfi.TAIFillInModel(8, 1, 3, 51, num_block=5, kf_dim=4)
+    m.apply(vfi.util.weights_init)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    clips = synthetic.make_clips(1, 15, 1, 128, 128, synthetic.SEEDS['cfg1'])
+    P, GT, Fo = (torch.from_numpy(x) for x in synthetic.split_clip(clips, 5, 5, 5))
+    with torch.no_grad():
+        ref = tai_oracle.tai_forward(sd, 1, 5, 51, 5, P, Fo)
+        out = m.to(DEV).eval()(5, P.to(DEV), Fo.to(DEV))
+    for k in KEYS:
+        d = (out[k].cpu() - ref[k]).abs()
+        assert float(d.max()) <= 2e-4, (k, float(d.max()))
+    p_gpu, s_gpu, _ = metrics.compute_errors(out['pred'].cpu().numpy(), GT.numpy())
+    p_cpu, s_cpu, _ = metrics.compute_errors(ref['pred'].numpy(), GT.numpy())
+    assert np.max(np.abs(p_gpu - p_cpu)) <= 0.01          # dB
+    assert np.max(np.abs(s_gpu - s_cpu)) <= 1e-4
+
+
+def test_direction_fusion_and_graph_replay_change_nothing():
+    torch.manual_seed(1)
+    m = vfi.TAIFillInModel(8, 3, 3, 51, num_block=4, kf_dim=4).to(DEV).eval()
+    clips = torch.from_numpy(synthetic.make_clips(2, 8, 3, 32, 32, 5)).to(DEV)
+    P, Fo = clips[:, :3], clips[:, 5:]
+    with torch.no_grad():
+        fused = {k: v.clone() for k, v in m(2, P, Fo).items()}
+        m.fuse_directions = False
+        split = m(2, P, Fo)
+        m.fuse_directions = True
+    for k in KEYS:
+        assert float((fused[k] - split[k]).abs().max()) <= 2e-5, k
+    g = GraphedForward(m, 2, P, Fo)
+    out = g(P, Fo)
+    for k in KEYS:
+        assert float((out[k] - fused[k]).abs().max()) <= 2e-5, k
+    out2 = g(P.flip(0), Fo.flip(0))                 # new inputs through the same graph
+    assert float((out2['pred'] - fused['pred'].flip(0)).abs().max()) <= 2e-5
+
+
+def test_eval_environment_protocol(tmp_path):
+    torch.manual_seed(2)
+    model = vfi.TAIFillInModel(4, 1, 3, 51, num_block=5, kf_dim=2)
+    os.makedirs(tmp_path / 'exp')
+    torch.save({'generator': model.state_dict()}, tmp_path / 'exp' / 'model_best.ckpt')
+    fresh = vfi.TAIFillInModel(4, 1, 3, 51, num_block=5, kf_dim=2)
+    env = create_eval_environment(fresh, str(tmp_path), 'exp', 'model_best.ckpt', [0, 0], device=DEV, use_graph=True)
+    clips = torch.from_numpy(synthetic.make_clips(2, 7, 1, 32, 32, 3))
+    env.set_test_inputs(clips[:, :2], clips[:, 5:])
+    env.T = 3
+    env.eval()
+    env.forward_test()
+    with torch.no_grad():
+        want = model.to(DEV).eval()(3, clips[:, :2].to(DEV), clips[:, 5:].to(DEV))['pred']
+    assert env.gen_output['pred'].shape == (2, 3, 1, 32, 32)
+    assert float((env.gen_output['pred'] - want).abs().max()) <= 2e-5
+    with pytest.raises(RuntimeError):
+        create_eval_environment(fresh, str(tmp_path), 'exp', 'missing.ckpt', [0, 0], device=DEV)
+
+
+def test_one_training_step_of_the_tai_environment(tmp_path):
+    torch.manual_seed(3)
+    np.random.seed(0)
+    model = vfi.TAIFillInModel(4, 1, 3, 51, num_block=5, kf_dim=2)
+    env = TAITrainingEnvironment(model, str(tmp_path), 'exp', [32, 32], 1, 1.0, 0.02, 1e-4, 0.5, 8, 3, 3, 3, 3, 3, [0, 0],
+                                 device=DEV)
+    env.sync_replicas()
+    clips = torch.from_numpy(synthetic.make_clips(2, 9, 1, 32, 32, 4))
+    K, T, F = env.sample_KTF(False)
+    env.set_train_inputs(clips[:, :K], clips[:, K + T:], clips[:, K:K + T])
+    env.K, env.T, env.F = K, T, F
+    before = {k: v.clone() for k, v in env.generator.state_dict().items()}
+    env.train()
+    env.forward_train()
+    env.optimize_parameters()
+    errs = env.get_current_errors()
+    assert set(errs) == {'G_loss', 'G_Lp', 'G_gdl', 'D_real', 'D_fake', 'G_GAN', 'G_Lp_forward', 'G_gdl_forward',
+                         'G_Lp_backward', 'G_gdl_backward'}
+    assert all(np.isfinite(v) for v in errs.values())
+    want = errs['G_Lp'] + errs['G_gdl'] + 0.02 * errs['G_GAN'] + errs['G_Lp_forward'] + errs['G_Lp_backward'] + \
+        errs['G_gdl_forward'] + errs['G_gdl_backward']
+    assert abs(errs['G_loss'] - want) <= 1e-5 * (1 + abs(want))           # environments.py:379,453
+    after = env.generator.state_dict()
+    moved = [k for k in before if not torch.equal(before[k], after[k])]
+    assert any(k.startswith('kernelnet.moduleVertical1') for k in moved) and any(k.startswith('generator.') for k in moved)
+    assert not any(k.startswith('merge_residual1') for k in moved)        # never evaluated, as in the reference
+    env.save('model_latest.ckpt', 1, 0, 0)
+    snap = torch.load(tmp_path / 'exp' / 'model_latest.ckpt', weights_only=False)
+    assert set(snap) == {'updates', 'sum_avg_psnr_err', 'sum_avg_ssim_err', 'generator', 'optimizer_G', 'discriminator',
+                         'optimizer_D'}

@@ -1,0 +1,158 @@
+"""Parity of the HIP separable convolution with the CPU oracle, through the C ABI (the autograd op calls
+tai_sepconv_forward / tai_sepconv_backward).  Tolerances (fp32): |d| <= 1e-5 (1+|ref|) forward,
+2e-5 gradients; the reference is the oracle accumulated in fp64, so the bound covers ANY fp32 summation order."""
+import numpy as np
+import pytest
+import torch
+
+import video_frame_inpainting_amd as vfi
+from video_frame_inpainting_amd import _native
+from video_frame_inpainting_amd import separable_convolution as sc
+from oracle import sepconv_oracle as so
+
+pytestmark = pytest.mark.gpu
+FWD_TOL, BWD_TOL = 1e-5, 2e-5
+DEV = 'cuda:0'
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(a.astype(np.float64) - b) / (1 + np.abs(b))))
+
+
+def _case(B, C, H, W, ks, seed):
+    g = torch.Generator().manual_seed(seed)
+    inp = torch.rand(B, C, H + ks - 1, W + ks - 1, generator=g) * 2 - 1          # tanh-range image
+    v = torch.randn(B, ks, H, W, generator=g) * 0.1
+    h = torch.randn(B, ks, H, W, generator=g) * 0.1
+    gO = torch.randn(B, C, H, W, generator=g)
+    return inp, v, h, gO
+
+
+def test_library_is_the_hip_build():
+    L = _native.lib()
+    assert L.tai_sepconv_version() >= 100
+
+
+SHAPES = [
+    (2, 1, 16, 128, 51),    # the fast path, gray
+    (1, 3, 12, 36, 51),     # ragged tile: H % 8 != 0, W < 128, RGB
+    (1, 2, 8, 132, 51),     # two column tiles, channel passes
+    (1, 1, 5, 7, 51),       # W % 4 != 0 -> generic kernels
+    (2, 3, 9, 10, 7),       # other kernel size -> generic kernels
+    (1, 1, 1, 4, 51),       # single row
+    (3, 1, 32, 32, 51),     # the golden-fixture size
+]
+
+
+@pytest.mark.parametrize('B,C,H,W,ks', SHAPES)
+def test_forward_and_backward_match_oracle(B, C, H, W, ks):
+    inp, v, h, gO = _case(B, C, H, W, ks, 11)
+    di, dv, dh = (t.to(DEV).requires_grad_() for t in (inp, v, h))
+    out = vfi.SeparableConvolution.apply(di, dv, dh, ks)
+    out.backward(gO.to(DEV))
+    ref = so.forward(inp.numpy(), v.numpy(), h.numpy(), ks, f64=True)
+    rI, rV, rH = so.backward(gO.numpy(), inp.numpy(), v.numpy(), h.numpy(), ks, f64=True)
+    assert _rel(out.detach().cpu().numpy(), ref) < FWD_TOL
+    assert _rel(di.grad.cpu().numpy(), rI) < BWD_TOL
+    assert _rel(dv.grad.cpu().numpy(), rV) < BWD_TOL
+    assert _rel(dh.grad.cpu().numpy(), rH) < BWD_TOL
+    # and the literal fp32 restatement of the reference's loops is within the same bound of the HIP result
+    lit = so.forward(inp.numpy(), v.numpy(), h.numpy(), ks)
+    assert _rel(out.detach().cpu().numpy(), lit.astype(np.float64)) < 2 * FWD_TOL
+
+
+@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize('C', [1, 3])
+def test_every_forward_variant(variant, C):
+    inp, v, h, _ = _case(2, C, 24, 128, 51, 5)
+    ref = so.forward(inp.numpy(), v.numpy(), h.numpy(), 51, f64=True)
+    prev = sc.set_forward_variant(variant)
+    try:
+        with torch.no_grad():
+            out = vfi.SeparableConvolution.apply(inp.to(DEV), v.to(DEV), h.to(DEV), 51)
+        assert _rel(out.cpu().numpy(), ref) < FWD_TOL
+    finally:
+        sc.set_forward_variant(prev)
+
+
+@pytest.mark.parametrize('i,j', [(0, 0), (50, 50), (25, 3), (1, 48), (49, 2)])
+def test_delta_taps_shift_exactly(i, j):
+    B, C, H, W, ks = 1, 1, 16, 128, 51
+    g = torch.Generator().manual_seed(3)
+    inp = torch.randn(B, C, H + ks - 1, W + ks - 1, generator=g)
+    v = torch.zeros(B, ks, H, W); v[:, i] = 1
+    h = torch.zeros(B, ks, H, W); h[:, j] = 1
+    with torch.no_grad():
+        out = vfi.SeparableConvolution.apply(inp.to(DEV), v.to(DEV), h.to(DEV), ks).cpu()
+    assert torch.equal(out, inp[:, :, i:i + H, j:j + W])          # bit-exact: every other product is an exact zero
+
+
+def test_box_taps_and_linearity_at_full_size():
+    # BASELINE cfg2 shape: too large for the oracle in a test, so use properties that do not depend on size
+    B, C, H, W, ks = 32, 1, 128, 128, 51
+    g = torch.Generator().manual_seed(8)
+    inp = (torch.rand(B, C, H + ks - 1, W + ks - 1, generator=g) * 2 - 1).to(DEV)
+    v = (torch.randn(B, ks, H, W, generator=g) * 0.1).to(DEV)
+    h = (torch.randn(B, ks, H, W, generator=g) * 0.1).to(DEV)
+    with torch.no_grad():
+        ones = torch.ones_like(v)
+        box = vfi.SeparableConvolution.apply(inp, ones, ones, ks)
+        ref = torch.nn.functional.avg_pool2d(inp.double(), ks, stride=1) * ks * ks
+        assert float(((box.double() - ref).abs() / (1 + ref.abs())).max()) < FWD_TOL
+        a = vfi.SeparableConvolution.apply(inp, v, h, ks)
+        b = vfi.SeparableConvolution.apply(inp, 2 * v, h, ks)           # linear in v (exact: power-of-two scale)
+        assert torch.equal(b, 2 * a)
+        c = vfi.SeparableConvolution.apply(0.5 * inp, v, 4 * h, ks)       # trilinear
+        assert torch.equal(c, 2 * a)
+        # a sample of pixels against the oracle on a 2-clip slice of the same tensors
+        sl = so.forward(inp[:2].cpu().numpy(), v[:2].cpu().numpy(), h[:2].cpu().numpy(), ks, f64=True)
+        assert _rel(a[:2].cpu().numpy(), sl) < FWD_TOL
+
+
+def test_adjoint_identity_at_full_size():
+    B, C, H, W, ks = 8, 1, 128, 128, 51
+    g = torch.Generator().manual_seed(9)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    inp, v, h = mk(B, C, H + ks - 1, W + ks - 1).requires_grad_(), (mk(B, ks, H, W) * 0.1).requires_grad_(), (mk(B, ks, H, W) * 0.1).requires_grad_()
+    gO = mk(B, C, H, W)
+    out = vfi.SeparableConvolution.apply(inp, v, h, ks)
+    out.backward(gO)
+    d_in, d_v, d_h = mk(*inp.shape), mk(*v.shape) * 0.1, mk(*h.shape) * 0.1
+    with torch.no_grad():
+        dot = lambda a, b: float((a.double() * b.double()).sum())
+        f = vfi.SeparableConvolution.apply
+        for lhs, rhs in ((dot(gO, f(d_in, v.detach(), h.detach(), ks)), dot(inp.grad, d_in)),
+                         (dot(gO, f(inp.detach(), d_v, h.detach(), ks)), dot(v.grad, d_v)),
+                         (dot(gO, f(inp.detach(), v.detach(), d_h, ks)), dot(h.grad, d_h))):
+            assert abs(lhs - rhs) <= 1e-4 * (1 + abs(lhs)), (lhs, rhs)
+
+
+def test_partial_gradients_and_error_reporting():
+    inp, v, h, gO = _case(1, 1, 8, 128, 51, 4)
+    di, dv, dh = inp.to(DEV), v.to(DEV).requires_grad_(), h.to(DEV)       # only gV requested
+    vfi.SeparableConvolution.apply(di, dv, dh, 51).backward(gO.to(DEV))
+    _, rV, _ = so.backward(gO.numpy(), inp.numpy(), v.numpy(), h.numpy(), 51, f64=True)
+    assert _rel(dv.grad.cpu().numpy(), rV) < BWD_TOL
+    L = _native.lib()
+    assert L.tai_sepconv_forward(None, None, None, None, 1, 1, 8, 8, 51, None) == -1      # TAI_SEPCONV_EINVAL
+    assert b'null' in L.tai_sepconv_last_error()
+    assert L.tai_sepconv_forward(di.data_ptr(), dv.data_ptr(), dh.data_ptr(), di.data_ptr(), 0, 1, 8, 8, 51, None) == -1
+
+
+def test_runs_on_a_side_stream_and_inside_a_graph():
+    inp, v, h, _ = _case(2, 1, 16, 128, 51, 6)
+    di, dv, dh = inp.to(DEV), v.to(DEV), h.to(DEV)
+    ref = so.forward(inp.numpy(), v.numpy(), h.numpy(), 51, f64=True)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.no_grad():
+        out = vfi.SeparableConvolution.apply(di, dv, dh, 51)
+    s.synchronize()
+    assert _rel(out.cpu().numpy(), ref) < FWD_TOL
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(graph):
+        gout = vfi.SeparableConvolution.apply(di, dv, dh, 51)
+    di.mul_(0.5)                      # replay must read the CURRENT contents of the captured buffers
+    graph.replay()
+    torch.cuda.synchronize()
+    assert _rel(gout.cpu().numpy(), 0.5 * ref) < FWD_TOL

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Training driver for the bi-TAI path: the step sequence of the reference's ``train.py:102-119`` (sample K,T,F ->
+slice the clip -> set_train_inputs -> train() -> forward_train() -> optimize_parameters()) on seeded synthetic clips,
+one process per GPU (data parallel over RCCL when launched with torch.distributed.run), with the reference's snapshot
+files ``model_latest.ckpt`` / ``model_%08d.ckpt`` (train.py:137-140).  TensorBoard logging, the video-list datasets and
+the periodic validation of the reference are dataset plumbing outside the hot path.
+
+  python train.py --name demo --K 5 --T 5 --F 5 --c_dim 1 --image_size 128 --batch_size 4 --model_key TAI_gray \
+      --max_iter 10 --synthetic 64
+"""
+import time
+
+import numpy as np
+import torch
+
+import video_frame_inpainting_amd as vfi
+from video_frame_inpainting_amd import parallel, synthetic
+from video_frame_inpainting_amd.environments import create_training_environment
+from video_frame_inpainting_amd.options import TrainOptions
+
+
+def main(args=None):
+    opt = TrainOptions().parse(args, allow_unknown=True)
+    rank, world, local_rank = parallel.init_from_env()
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    n_clips = opt.synthetic or 64
+    H, W = opt.image_size[0] + opt.padding_size[0], opt.image_size[1] + opt.padding_size[1]
+    clips = torch.from_numpy(synthetic.make_clips(n_clips, opt.K + opt.T + opt.F, opt.c_dim, H, W, opt.seed + rank))
+
+    torch.manual_seed(0)
+    np.random.seed(0)          # identical (K, T, F) draws on every rank
+    model = vfi.create_model(opt.model_key)
+    env = create_training_environment(model, opt.c_dim, opt.checkpoints_dir, opt.name, opt.K, opt.T, opt.F,
+                                      opt.image_size, opt.alpha, opt.beta, opt.lr, opt.beta1, opt.df_dim, opt.Ip,
+                                      opt.disc_window_size, opt.padding_size, device=device)
+    env.sync_replicas()
+    total_updates = env.start_update
+    order = np.random.RandomState(opt.seed + 7 * rank)
+    while total_updates < opt.max_iter:
+        t0 = time.time()
+        total_updates += 1
+        env.total_updates = total_updates
+        K, T, F = env.sample_KTF(opt.sample_KTF)
+        idx = order.randint(0, n_clips, opt.batch_size)
+        all_frames = clips[idx]
+        env.set_train_inputs(all_frames[:, :K], all_frames[:, K + T:K + T + F], all_frames[:, K:K + T])
+        env.K, env.T, env.F = K, T, F
+        env.train()
+        env.forward_train()
+        env.optimize_parameters()
+        if total_updates % opt.print_freq == 0 or total_updates == 1:
+            torch.cuda.synchronize()
+            errs = env.get_current_errors()
+            if rank == 0:
+                print('iter %d (K,T,F)=(%d,%d,%d) %.3fs  %s' % (total_updates, K, T, F, time.time() - t0,
+                                                                ' '.join('%s=%.5f' % kv for kv in sorted(errs.items()))))
+        if total_updates % opt.save_latest_freq == 0:
+            env.save('model_latest.ckpt', total_updates, 0, 0)
+            env.save('model_%08d.ckpt' % total_updates, total_updates, 0, 0)
+    env.save('model_latest.ckpt', total_updates, 0, 0)
+    print('Done.')
+
+
+if __name__ == '__main__':
+    main()

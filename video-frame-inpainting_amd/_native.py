@@ -1,0 +1,81 @@
+"""Loader (and in-tree builder) of the C-ABI HIP library ``libtai_sepconv.so``.
+
+The library is the product's only compute backend for the separable convolution: there is no CPU or
+eager-PyTorch fallback.  ``lib()`` raises if the shared object is missing or lacks a symbol that
+``include/tai_sepconv.h`` declares.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, 'libtai_sepconv.so')
+HEADER = os.path.join(_ROOT, 'include', 'tai_sepconv.h')
+SOURCES = [os.path.join(_PKG, 'csrc', f) for f in
+           ('sepconv_capi.hip', 'sepconv_fwd.hip.inc', 'sepconv_bwd.hip.inc', 'sepconv_fwd_rowloop.inc')]
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Function names declared in include/tai_sepconv.h."""
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(tai_sepconv_\w+)\s*\(', text)))
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> video-frame-inpainting_amd/libtai_sepconv.so (cross-compiles without a GPU)."""
+    newest = max(os.path.getmtime(p) for p in SOURCES + [HEADER])
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
+        return LIB_PATH
+    gen = os.path.join(_ROOT, 'tools', 'gen_fwd_asm.py')
+    if os.path.exists(gen) and os.path.getmtime(gen) > os.path.getmtime(SOURCES[3]):
+        subprocess.check_call(['python3', gen], stdout=subprocess.DEVNULL)
+    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-slp-vectorize', '-w',
+           '-I' + os.path.join(_ROOT, 'include'), '-o', LIB_PATH, SOURCES[0]]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            '%s is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(there is no fallback path for the separable convolution)' % LIB_PATH)
+    import torch  # noqa: F401  -- load torch's HIP runtime first so this library binds to the same libamdhip64
+    L = ctypes.CDLL(LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(L, s)]
+    if missing:
+        raise NativeLibraryError('%s does not export %s' % (LIB_PATH, missing))
+    P, I, V = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
+    L.tai_sepconv_forward.argtypes = [P, P, P, P, I, I, I, I, I, V]
+    L.tai_sepconv_forward.restype = I
+    L.tai_sepconv_backward.argtypes = [P, P, P, P, P, P, P, I, I, I, I, I, V]
+    L.tai_sepconv_backward.restype = I
+    L.tai_sepconv_set_forward_variant.argtypes = [I]
+    L.tai_sepconv_set_forward_variant.restype = I
+    L.tai_sepconv_forward_bytes.argtypes = [I] * 5
+    L.tai_sepconv_forward_bytes.restype = ctypes.c_longlong
+    L.tai_sepconv_backward_bytes.argtypes = [I] * 5
+    L.tai_sepconv_backward_bytes.restype = ctypes.c_longlong
+    L.tai_sepconv_last_error.restype = ctypes.c_char_p
+    L.tai_sepconv_version.restype = I
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, lib().tai_sepconv_last_error().decode()))

@@ -1,0 +1,307 @@
+"""Evaluation and training environments of the bi-TAI path (reference src/environments/environments.py:55-485).
+
+Same object protocol as the reference so ``predict.py`` / ``train.py``-style drivers read the same:
+  eval:   env = create_eval_environment(model, checkpoints_dir, name, snapshot_file_name, padding_size)
+          env.set_test_inputs(P, F); env.T = T; env.eval(); env.forward_test(); env.gen_output['pred']
+  train:  env = create_training_environment(...); env.set_train_inputs(P, F, GT); env.K, env.T, env.F = ...
+          env.train(); env.forward_train(); env.optimize_parameters(); env.get_current_errors()
+Checkpoints keep the reference's dict layout {updates, sum_avg_psnr_err, sum_avg_ssim_err, generator, optimizer_G,
+discriminator, optimizer_D} (environments.py:178-194, 290-297); evaluation loads ``snapshot['generator']`` only (:113).
+
+What differs (same arithmetic):
+  * no ``Variable`` / ``volatile``: inference runs under ``torch.no_grad()`` and, with ``use_graph=True``, as a replayed
+    hipGraph (graph.py) keyed by the input shapes;
+  * the device is explicit, so one process per GPU can own ``cuda:LOCAL_RANK``;
+  * ``optimize_parameters`` all-reduces generator and discriminator gradients across data-parallel ranks (parallel.py)
+    right after each backward, in the reference's G-then-D order; with one process it is the reference's step.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import parallel
+from .graph import GraphedForward
+from .losses import GDL
+from .mcnet import MCNetFillInModel
+from .sn_discriminator import SNDiscriminator
+from .tai import TAIFillInModel
+from .util import inverse_transform, move_to_devices, weights_init
+
+
+def create_eval_environment(fill_in_model, checkpoints_dir, name, snapshot_file_name, padding_size, device=None,
+                            load_snapshot=True, use_graph=False):
+    env = BaseVideoFillInEnvironment(fill_in_model, checkpoints_dir, name, padding_size, device=device,
+                                     use_graph=use_graph)
+    if load_snapshot:
+        env.load(snapshot_file_name)
+    print('Loaded evaluation environment')
+    return env
+
+
+def create_training_environment(fill_in_model, c_dim, checkpoints_dir, name, max_K, max_T, max_F, image_size, alpha,
+                                beta, lr, beta1, df_dim, Ip, disc_window_size, padding_size, device=None):
+    if isinstance(fill_in_model, TAIFillInModel):
+        env = TAITrainingEnvironment(fill_in_model, checkpoints_dir, name, image_size, c_dim, alpha, beta, lr, beta1,
+                                     df_dim, Ip, disc_window_size, max_K, max_T, max_F, padding_size, device=device)
+    elif isinstance(fill_in_model, MCNetFillInModel):
+        env = MCNetTrainingEnvironment(fill_in_model, checkpoints_dir, name, image_size, c_dim, alpha, beta, lr, beta1,
+                                       df_dim, Ip, disc_window_size, max_K, max_T, max_F, padding_size, device=device)
+    else:
+        raise RuntimeError('Tried to create a training environment for object of unsupported type %s'
+                           % type(fill_in_model).__name__)
+    if os.path.isfile(os.path.join(checkpoints_dir, name, 'model_latest.ckpt')):
+        print('Loading latest snapshot...')
+        env.load('model_latest.ckpt')
+    print('Loaded training environment')
+    return env
+
+
+class BaseVideoFillInEnvironment(object):
+    """environments.py:64-119."""
+
+    def __init__(self, video_fill_in_model, checkpoints_dir, name, padding_size, device=None, use_graph=False):
+        self.save_dir = os.path.join(checkpoints_dir, name)
+        self.padding_size = padding_size
+        self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self.generator = move_to_devices(video_fill_in_model, self.device)
+        self.generator.apply(weights_init)
+        self.K = self.T = self.F = None
+        self.use_graph = use_graph
+        self._graphs = {}
+
+    def set_test_inputs(self, preceding_frames, following_frames):
+        self.preceding_frames = preceding_frames.contiguous().to(self.device, non_blocking=True)
+        self.following_frames = following_frames.contiguous().to(self.device, non_blocking=True)
+
+    def set_gt_middle_frames_test(self, gt_middle_frames):
+        self.gt_middle_frames = gt_middle_frames.contiguous().to(self.device, non_blocking=True)
+
+    def forward_test(self):
+        if self.use_graph:
+            key = (self.T, tuple(self.preceding_frames.shape), tuple(self.following_frames.shape))
+            if key not in self._graphs:
+                self._graphs[key] = GraphedForward(self.generator, self.T, self.preceding_frames, self.following_frames)
+            self.gen_output = self._graphs[key](self.preceding_frames, self.following_frames)
+        else:
+            with torch.no_grad():
+                self.gen_output = self.generator(self.T, self.preceding_frames, self.following_frames)
+
+    def load(self, snapshot_file_name):
+        save_path = os.path.join(self.save_dir, snapshot_file_name)
+        if os.path.isfile(save_path):
+            print('=> loading snapshot from {}'.format(save_path))
+            snapshot = torch.load(save_path, map_location=self.device, weights_only=False)
+        else:
+            raise RuntimeError('Failed to find snapshot at path %s' % save_path)
+        self.generator.load_state_dict(snapshot['generator'])
+        self._graphs.clear()
+        return snapshot
+
+    def eval(self):
+        self.generator.eval()
+
+
+class BaseTrainingEnvironment(BaseVideoFillInEnvironment):
+    """environments.py:122-259."""
+
+    def __init__(self, fill_in_model, checkpoints_dir, name, lr, beta1, max_K, max_T, max_F, padding_size, device=None):
+        super().__init__(fill_in_model, checkpoints_dir, name, padding_size, device=device)
+        self.start_update = 0
+        self.total_updates = 0
+        self.start_sum_avg_psnr_err = 0
+        self.start_sum_avg_ssim_err = 0
+        self.max_K, self.max_T, self.max_F = max_K, max_T, max_F
+        self.optimizer_G = torch.optim.Adam(self.generator.parameters(), lr=lr, betas=(beta1, 0.999))
+        self._reducer_G = parallel.GradAllReducer(self.generator.parameters())
+        self._ktf_rng = np.random       # global numpy RNG as in the reference; seed it identically on every rank
+
+    def sample_KTF(self, allow_random_sampling):
+        if allow_random_sampling:
+            K = self._ktf_rng.randint(1, self.max_K + 1)
+            T = self._ktf_rng.randint(1, self.max_T + 1)
+            F = self._ktf_rng.randint(1, self.max_F + 1)
+        else:
+            K, T, F = self.max_K, self.max_T, self.max_F
+        return K, T, F
+
+    def set_train_inputs(self, preceding_frames, following_frames, gt_middle_frames):
+        self.preceding_frames = preceding_frames.contiguous().to(self.device, non_blocking=True)
+        self.following_frames = following_frames.contiguous().to(self.device, non_blocking=True)
+        self.gt_middle_frames = gt_middle_frames.contiguous().to(self.device, non_blocking=True)
+
+    def forward_train(self):
+        self.gen_output = self.generator(self.T, self.preceding_frames, self.following_frames)
+
+    def get_current_state_dict(self, total_updates, sum_avg_psnr_err, sum_avg_ssim_err):
+        return {
+            'updates': total_updates,
+            'sum_avg_psnr_err': sum_avg_psnr_err,
+            'sum_avg_ssim_err': sum_avg_ssim_err,
+            'generator': self.generator.state_dict(),
+            'optimizer_G': self.optimizer_G.state_dict(),
+        }
+
+    def load(self, snapshot_file_name):
+        snapshot = super().load(snapshot_file_name)
+        self.start_update = snapshot['updates']
+        self.start_sum_avg_psnr_err = snapshot['sum_avg_psnr_err']
+        self.start_sum_avg_ssim_err = snapshot['sum_avg_ssim_err']
+        self.optimizer_G.load_state_dict(snapshot['optimizer_G'])
+        return snapshot
+
+    def save(self, snapshot_file_name, total_updates, sum_avg_psnr_err, sum_avg_ssim_err):
+        if parallel.rank() != 0:
+            return
+        os.makedirs(self.save_dir, exist_ok=True)
+        torch.save(self.get_current_state_dict(total_updates, sum_avg_psnr_err, sum_avg_ssim_err),
+                   os.path.join(self.save_dir, snapshot_file_name))
+
+    def optimize_parameters(self):
+        self.optimizer_G.zero_grad()
+        self.compute_loss_G()
+        self.loss_G.backward()
+        self._reducer_G.allreduce_()
+        self.optimizer_G.step()
+
+    def compute_loss_G(self):
+        self.loss_G = torch.zeros(1, device=self.device)
+
+    def get_current_errors(self):
+        return {'G_loss': float(self.loss_G.item())}
+
+    def train(self):
+        self.generator.train()
+
+
+class L2GDLDiscTrainingEnvironment(BaseTrainingEnvironment):
+    """environments.py:262-397: loss_G = alpha (MSE + GDL)(pred) + beta BCE(D(cat[P, pred, F]), 1);
+    loss_D = BCE(D(fake.detach()), window labels) + BCE(D(real), 1)."""
+
+    def __init__(self, fill_in_model, checkpoints_dir, name, image_size, c_dim, alpha, beta, lr, beta1, df_dim, Ip,
+                 disc_t, max_K, max_T, max_F, padding_size, device=None):
+        super().__init__(fill_in_model, checkpoints_dir, name, lr, beta1, max_K, max_T, max_F, padding_size, device=device)
+        self.loss_Lp = torch.nn.MSELoss()
+        self.loss_gdl = GDL()
+        self.loss_d = torch.nn.BCEWithLogitsLoss()
+        self.alpha, self.beta, self.disc_t = alpha, beta, disc_t
+        discriminator = SNDiscriminator((image_size[0] + padding_size[0], image_size[1] + padding_size[1]), c_dim,
+                                        disc_t, df_dim, Ip)
+        discriminator = move_to_devices(discriminator, self.device)
+        discriminator.apply(weights_init)
+        self.discriminator = discriminator
+        self.optimizer_D = torch.optim.Adam(self.discriminator.parameters(), lr=lr, betas=(beta1, 0.999))
+        self._reducer_D = parallel.GradAllReducer(self.discriminator.parameters())
+
+    def sync_replicas(self):
+        """Data-parallel start-up: identical weights and identical SN ``u`` vectors on every rank (rank 0's)."""
+        parallel.materialise_sn_vectors(self.discriminator)
+        parallel.broadcast_module_state(self.generator)
+        parallel.broadcast_module_state(self.discriminator)
+
+    def get_current_state_dict(self, total_updates, sum_avg_psnr_err, sum_avg_ssim_err):
+        state = super().get_current_state_dict(total_updates, sum_avg_psnr_err, sum_avg_ssim_err)
+        state['discriminator'] = self.discriminator.state_dict()
+        state['optimizer_D'] = self.optimizer_D.state_dict()
+        return state
+
+    def load(self, snapshot_file_name):
+        snapshot = super().load(snapshot_file_name)
+        self.discriminator.load_state_dict(snapshot['discriminator'])
+        self.optimizer_D.load_state_dict(snapshot['optimizer_D'])
+        return snapshot
+
+    def create_fake_labels(self):
+        """1 for windows made of real frames only (both ends), 0 for every window touching a generated frame
+        (environments.py:308-323) -> [K+T+F-disc_t+1]."""
+        ones_p = max(0, self.K - self.disc_t + 1)
+        ones_f = max(0, self.F - self.disc_t + 1)
+        n = self.K + self.T + self.F - self.disc_t + 1
+        labels = torch.zeros(n)
+        labels[:ones_p] = 1
+        if ones_f > 0:
+            labels[n - ones_f:] = 1
+        return labels
+
+    def compute_loss_D(self):
+        fake = torch.cat([self.preceding_frames, self.gen_output['pred'], self.following_frames], dim=1).detach()
+        h = self.discriminator(fake)
+        labels = self.create_fake_labels().to(self.device).view(1, -1).expand(fake.size(0), -1)
+        self.loss_d_fake = self.loss_d(h, labels)
+        real = torch.cat([self.preceding_frames, self.gt_middle_frames, self.following_frames], dim=1).detach()
+        h_ = self.discriminator(real)
+        self.loss_d_real = self.loss_d(h_, torch.ones_like(h_))
+        self.loss_D = self.loss_d_fake + self.loss_d_real
+
+    def optimize_parameters(self):
+        super().optimize_parameters()
+        self.optimizer_D.zero_grad()
+        self.compute_loss_D()
+        self.loss_D.backward()
+        self._reducer_D.allreduce_()
+        self.optimizer_D.step()
+
+    @staticmethod
+    def _time_major_01(x):
+        """[B,T,C,H,W] in [-1,1] -> [T*B,C,H,W] in [0,1] (environments.py:363-368)."""
+        _, _, c, H, W = x.shape
+        return inverse_transform(x.permute(1, 0, 2, 3, 4).contiguous().view(-1, c, H, W))
+
+    def compute_loss_G(self):
+        super().compute_loss_G()
+        gt = self._time_major_01(self.gt_middle_frames)
+        outputs = self._time_major_01(self.gen_output['pred'])
+        self.Lp = self.loss_Lp(outputs, gt)
+        self.gdl = self.loss_gdl(outputs, gt)
+        fake = torch.cat([self.preceding_frames, self.gen_output['pred'], self.following_frames], dim=1)
+        h = self.discriminator(fake)
+        self.L_GAN = self.loss_d(h, torch.ones_like(h))
+        self.loss_G = self.loss_G + self.alpha * (self.Lp + self.gdl) + self.beta * self.L_GAN
+
+    def get_current_errors(self):
+        d = super().get_current_errors()
+        d.update({'G_Lp': float(self.Lp.item()), 'G_gdl': float(self.gdl.item()),
+                  'D_real': float(self.loss_d_real.item()), 'D_fake': float(self.loss_d_fake.item()),
+                  'G_GAN': float(self.L_GAN.item())})
+        return d
+
+    def train(self):
+        super().train()
+        self.discriminator.train()
+
+
+class MCNetTrainingEnvironment(L2GDLDiscTrainingEnvironment):
+    """environments.py:400-412."""
+
+    def sample_KTF(self, allow_random_sampling):
+        if allow_random_sampling:
+            return (self._ktf_rng.randint(2, self.max_K + 1), self._ktf_rng.randint(1, self.max_T + 1),
+                    self._ktf_rng.randint(1, self.max_F + 1))
+        return self.max_K, self.max_T, self.max_F
+
+
+class TAITrainingEnvironment(L2GDLDiscTrainingEnvironment):
+    """environments.py:415-485: adds alpha (MSE + GDL) on the forward and on the backward intermediate prediction."""
+
+    def sample_KTF(self, allow_random_sampling):
+        if allow_random_sampling:
+            return (self._ktf_rng.randint(2, self.max_K + 1), self._ktf_rng.randint(1, self.max_T + 1),
+                    self._ktf_rng.randint(2, self.max_F + 1))
+        return self.max_K, self.max_T, self.max_F
+
+    def compute_loss_G(self):
+        super().compute_loss_G()
+        gt = self._time_major_01(self.gt_middle_frames)
+        out_f = self._time_major_01(self.gen_output['pred_forward'])
+        out_b = self._time_major_01(self.gen_output['pred_backward'])
+        self.Lp_forward = self.loss_Lp(out_f, gt)
+        self.Lp_backward = self.loss_Lp(out_b, gt)
+        self.gdl_forward = self.loss_gdl(out_f, gt)
+        self.gdl_backward = self.loss_gdl(out_b, gt)
+        self.loss_G = self.loss_G + self.alpha * (self.Lp_forward + self.Lp_backward + self.gdl_forward + self.gdl_backward)
+
+    def get_current_errors(self):
+        d = super().get_current_errors()
+        d.update({'G_Lp_forward': float(self.Lp_forward.item()), 'G_gdl_forward': float(self.gdl_forward.item()),
+                  'G_Lp_backward': float(self.Lp_backward.item()), 'G_gdl_backward': float(self.gdl_backward.item())})
+        return d

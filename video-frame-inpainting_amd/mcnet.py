@@ -1,0 +1,231 @@
+"""MC-Net generator blocks (Villegas et al.) as used by bi-TAI: the MI355X-side mirror of the reference's
+``src/models/mcnet/mcnet.py``.
+
+State-dict keys are the reference's (so ``snapshot['generator']`` loads unchanged, environments.py:113):
+``motion_enc.dyn_conv{1.0,2.1,3.1}``, ``conv_lstm_cell.conv``, ``content_enc.cont_conv{1.0,1.2,2.1,2.3,3.1,3.3,3.5}``,
+``comb_layers.h_comb.{0,2,4}``, ``residual{1,2,3}.res.{0,2}``, ``dec_cnn.dec3.{0,2,4}``, ``dec_cnn.dec2.{0,2}``,
+``dec_cnn.dec1.{0,2}``.  The convolutions ride MIOpen through ``torch.nn.functional``; everything around them is
+arranged for a static, graph-capturable schedule:
+  * layers are kept in ``IndexedConvs`` containers that own only the parameterised layers (at the reference's
+    Sequential indices) and run conv+activation chains without Python-side module dispatch per activation;
+  * the reference's ``fixed_unpooling`` (zero-stuffed 2x upsample via permute/cat/view, mcnet.py:240-256) followed by
+    ``+ res`` is one strided in-place add into a copy of the residual;
+  * ``ConvTranspose2d(k=3, s=1, p=1)`` runs as the equivalent direct convolution with the transposed, flipped kernel
+    (MIOpen's forward-conv path), keeping the reference's [in, out, 3, 3] parameter layout;
+  * the ConvLSTM state is allocated on the input's device with integer H//8 x W//8 (the reference relies on Py2
+    integer division, mcnet.py:278,384).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .util import gray01
+
+
+class IndexedConvs(nn.Module):
+    """Conv layers registered under explicit integer names, e.g. {0, 2, 4} or {1}, matching the indices the
+    reference's nn.Sequential gave them (activations and pools own no parameters and are not modules here)."""
+
+    def __init__(self, layers):
+        super().__init__()
+        self.order = []
+        for index, layer in layers:
+            self.add_module(str(index), layer)
+            self.order.append(str(index))
+
+    def convs(self):
+        return [getattr(self, k) for k in self.order]
+
+
+def _conv_relu_chain(x, convs, last_act='relu'):
+    for i, c in enumerate(convs):
+        x = c(x)
+        if i + 1 < len(convs) or last_act == 'relu':
+            x = torch.relu_(x) if not x.requires_grad else torch.relu(x)
+        elif last_act == 'tanh':
+            x = torch.tanh(x)
+    return x
+
+
+def _convt3x3_as_conv(x, layer):
+    # ConvTranspose2d(cin, cout, 3, stride 1, padding 1)  ==  conv2d with weight[o, i, ky, kx] = wt[i, o, 2-ky, 2-kx]
+    w = layer.weight.transpose(0, 1).flip(2, 3)
+    return F.conv2d(x, w, layer.bias, stride=1, padding=1)
+
+
+def unpool2x_add(x, res):
+    """fixed_unpooling(x) + res  (mcnet.py:234-236, 240-256): x lands on the even (2i, 2j) sites."""
+    out = res.clone()
+    out[:, :, 0::2, 0::2] += x
+    return out
+
+
+class MotionEnc(nn.Module):
+    """mcnet.py:14-60: conv5x5(1->gf)+ReLU; pool, conv5x5(gf->2gf)+ReLU; pool, conv7x7(2gf->4gf)+ReLU; pool."""
+
+    def __init__(self, gf_dim):
+        super().__init__()
+        self.dyn_conv1 = IndexedConvs([(0, nn.Conv2d(1, gf_dim, 5, padding=2))])
+        self.dyn_conv2 = IndexedConvs([(1, nn.Conv2d(gf_dim, gf_dim * 2, 5, padding=2))])
+        self.dyn_conv3 = IndexedConvs([(1, nn.Conv2d(gf_dim * 2, gf_dim * 4, 7, padding=3))])
+
+    def forward(self, input_diff):
+        c1 = _conv_relu_chain(input_diff, self.dyn_conv1.convs())
+        c2 = _conv_relu_chain(F.max_pool2d(c1, 2), self.dyn_conv2.convs())
+        c3 = _conv_relu_chain(F.max_pool2d(c2, 2), self.dyn_conv3.convs())
+        return F.max_pool2d(c3, 2), [c1, c2, c3]
+
+
+class ContentEnc(nn.Module):
+    """mcnet.py:63-119: VGG-like 3x3 stacks C->gf->gf /2 ->2gf->2gf /2 ->4gf->4gf->4gf /2."""
+
+    def __init__(self, c_dim, gf_dim):
+        super().__init__()
+        g = gf_dim
+        self.cont_conv1 = IndexedConvs([(0, nn.Conv2d(c_dim, g, 3, padding=1)), (2, nn.Conv2d(g, g, 3, padding=1))])
+        self.cont_conv2 = IndexedConvs([(1, nn.Conv2d(g, g * 2, 3, padding=1)), (3, nn.Conv2d(g * 2, g * 2, 3, padding=1))])
+        self.cont_conv3 = IndexedConvs([(1, nn.Conv2d(g * 2, g * 4, 3, padding=1)), (3, nn.Conv2d(g * 4, g * 4, 3, padding=1)),
+                                        (5, nn.Conv2d(g * 4, g * 4, 3, padding=1))])
+
+    def forward(self, raw):
+        c1 = _conv_relu_chain(raw, self.cont_conv1.convs())
+        c2 = _conv_relu_chain(F.max_pool2d(c1, 2), self.cont_conv2.convs())
+        c3 = _conv_relu_chain(F.max_pool2d(c2, 2), self.cont_conv3.convs())
+        return F.max_pool2d(c3, 2), [c1, c2, c3]
+
+
+class CombLayers(nn.Module):
+    """mcnet.py:122-153: cat(h_dyn, h_cont) -> 8gf->4gf->2gf->4gf, 3x3 + ReLU each."""
+
+    def __init__(self, gf_dim):
+        super().__init__()
+        g = gf_dim
+        self.h_comb = IndexedConvs([(0, nn.Conv2d(g * 8, g * 4, 3, padding=1)), (2, nn.Conv2d(g * 4, g * 2, 3, padding=1)),
+                                    (4, nn.Conv2d(g * 2, g * 4, 3, padding=1))])
+
+    def forward(self, h_dyn, h_cont):
+        return _conv_relu_chain(torch.cat((h_dyn, h_cont), dim=1), self.h_comb.convs())
+
+
+class Residual(nn.Module):
+    """mcnet.py:156-185: cat -> conv3x3 + ReLU -> conv3x3 (no final activation)."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.res = IndexedConvs([(0, nn.Conv2d(in_dim, out_dim, 3, padding=1)), (2, nn.Conv2d(out_dim, out_dim, 3, padding=1))])
+
+    def forward(self, input_dyn, input_cont):
+        return _conv_relu_chain(torch.cat((input_dyn, input_cont), dim=1), self.res.convs(), last_act=None)
+
+
+class DecCnn(nn.Module):
+    """mcnet.py:188-256: three unpool(+residual) stages of 3x3 transposed convs, ReLU inside, Tanh at the end."""
+
+    def __init__(self, c_dim, gf_dim):
+        super().__init__()
+        g = gf_dim
+        T = lambda i, o: nn.ConvTranspose2d(i, o, 3, padding=1)
+        self.dec3 = IndexedConvs([(0, T(g * 4, g * 4)), (2, T(g * 4, g * 4)), (4, T(g * 4, g * 2))])
+        self.dec2 = IndexedConvs([(0, T(g * 2, g * 2)), (2, T(g * 2, g))])
+        self.dec1 = IndexedConvs([(0, T(g, g)), (2, T(g, c_dim))])
+
+    @staticmethod
+    def _stage(x, layers, last_act):
+        for i, layer in enumerate(layers):
+            x = _convt3x3_as_conv(x, layer)
+            x = torch.tanh(x) if (last_act == 'tanh' and i + 1 == len(layers)) else torch.relu(x)
+        return x
+
+    def forward(self, comb, res1, res2, res3):
+        x = self._stage(unpool2x_add(comb, res3), self.dec3.convs(), 'relu')
+        x = self._stage(unpool2x_add(x, res2), self.dec2.convs(), 'relu')
+        return self._stage(unpool2x_add(x, res1), self.dec1.convs(), 'tanh')
+
+    fixed_unpooling = staticmethod(lambda x: unpool2x_add(x, x.new_zeros(x.shape[0], x.shape[1], 2 * x.shape[2], 2 * x.shape[3])))
+
+
+class ConvLstmCell(nn.Module):
+    """mcnet.py:259-294.  state = cat(c, h); gates (i, j, f, o) = chunks of conv(cat(input, h));
+    c' = c * sigmoid(f + forget_bias) + sigmoid(i) * tanh(j);  h' = tanh(c') * sigmoid(o)."""
+
+    def __init__(self, feature_size, num_features, forget_bias=1, bias=True):
+        super().__init__()
+        self.feature_size = feature_size
+        self.num_features = num_features
+        self.forget_bias = forget_bias
+        self.conv = nn.Conv2d(num_features * 2, num_features * 4, feature_size, padding=(feature_size - 1) // 2, bias=bias)
+
+    def forward(self, input, state):
+        c, h = torch.chunk(state, 2, dim=1)
+        gates = self.conv(torch.cat((input, h), dim=1))
+        i, j, f, o = torch.chunk(gates, 4, dim=1)
+        new_c = c * torch.sigmoid(f + self.forget_bias) + torch.sigmoid(i) * torch.tanh(j)
+        new_h = torch.tanh(new_c) * torch.sigmoid(o)
+        return new_h, torch.cat((new_c, new_h), dim=1)
+
+
+class MCNet(nn.Module):
+    """mcnet.py:350-453: K-1 motion-encoder/ConvLSTM steps over the given difference frames, then T autoregressive
+    steps (content encoder, combination layers, residuals, decoder), feeding gray(x_hat) - gray(x_t) back in."""
+
+    def __init__(self, gf_dim, c_dim, feature_size, forget_bias=1, bias=True):
+        super().__init__()
+        self.c_dim = c_dim
+        self.gf_dim = gf_dim
+        self.motion_enc = MotionEnc(gf_dim)
+        self.conv_lstm_cell = ConvLstmCell(feature_size, 4 * gf_dim, forget_bias=forget_bias, bias=bias)
+        self.content_enc = ContentEnc(c_dim, gf_dim)
+        self.comb_layers = CombLayers(gf_dim)
+        self.residual3 = Residual(gf_dim * 8, gf_dim * 4)
+        self.residual2 = Residual(gf_dim * 4, gf_dim * 2)
+        self.residual1 = Residual(gf_dim * 2, gf_dim * 1)
+        self.dec_cnn = DecCnn(c_dim, gf_dim)
+
+    def get_initial_conv_lstm_state(self, batch_size, image_size, like):
+        return like.new_zeros(batch_size, 8 * self.gf_dim, image_size[0] // 8, image_size[1] // 8)
+
+    def forward(self, K, T, diff_in, xt):
+        """diff_in [B, K-1, 1, H, W] gray differences; xt [B, C, H, W] last known frame.
+        Returns lists pred[T], dyn[T], cont[T], res[T] = [res1, res2, res3]."""
+        assert K >= 2, 'MC-Net needs at least two input frames (one difference frame)'
+        diffs = [diff_in[:, t] for t in range(diff_in.shape[1])]
+        state = self.get_initial_conv_lstm_state(xt.shape[0], xt.shape[2:4], xt)
+        h_dyn = res_m = None
+        for t in range(K - 1):
+            enc_h, res_m = self.motion_enc(diffs[t])
+            h_dyn, state = self.conv_lstm_cell(enc_h, state)
+        pred, dyn, cont, res = [], [], [], []
+        xt_gray = gray01(xt)
+        for t in range(T):
+            if t > 0:
+                enc_h, res_m = self.motion_enc(diffs[-1])
+                h_dyn, state = self.conv_lstm_cell(enc_h, state)
+            h_cont, res_c = self.content_enc(xt)
+            h_tpl = self.comb_layers(h_dyn, h_cont)
+            dyn.append(h_dyn)
+            cont.append(h_cont)
+            res_1 = self.residual1(res_m[0], res_c[0])
+            res_2 = self.residual2(res_m[1], res_c[1])
+            res_3 = self.residual3(res_m[2], res_c[2])
+            res.append([res_1, res_2, res_3])
+            x_hat = self.dec_cnn(h_tpl, res_1, res_2, res_3)
+            x_hat_gray = gray01(x_hat)
+            diffs.append(x_hat_gray - xt_gray)
+            xt, xt_gray = x_hat, x_hat_gray
+            pred.append(x_hat)
+        return pred, dyn, cont, res
+
+
+class MCNetFillInModel(nn.Module):
+    """mcnet.py:301-347: forward-only MC-Net baseline behind the fill-in model interface."""
+
+    def __init__(self, gf_dim, c_dim, feature_size, forget_bias=1, bias=True):
+        super().__init__()
+        self.c_dim = c_dim
+        self.generator = MCNet(gf_dim, c_dim, feature_size, forget_bias=forget_bias, bias=bias)
+
+    def forward(self, T, preceding_frames, following_frames):
+        K = preceding_frames.size(1)
+        gray = gray01(preceding_frames)
+        pred, _, _, _ = self.generator(K, T, gray[:, 1:] - gray[:, :-1], preceding_frames[:, -1])
+        return {'pred': torch.stack(pred, dim=1)}

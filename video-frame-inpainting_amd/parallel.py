@@ -1,0 +1,114 @@
+"""Data parallelism for the bi-TAI path: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI on
+ROCm; "gloo" on CPU for the tests).  The reference is single-GPU (no collective anywhere), so this is new
+capability shaped by the path itself:
+
+  * inference shards CLIPS: every rank runs the same weights on its own slice of the batch; there is no collective on
+    the data path (clips are independent: no BatchNorm, nothing crosses the batch dimension);
+  * training adds exactly two gradient all-reduces per step, in the reference's G-then-D order (environments.py:348-355):
+    generator grads (38.3 M fp32 = 153 MB for TAI_gray) after ``loss_G.backward()`` and discriminator grads (2.8 M fp32)
+    after ``loss_D.backward()``.  Gradients are packed into a few LARGE flat buckets (default 64 MB): xGMI is
+    point-to-point, a ring all-reduce is per-link bound (2*(N-1)/N * bytes / ~153 GB/s), so fewer, larger messages
+    amortise the per-collective latency; at 153 MB the ring costs ~1.9 ms against a multi-hundred-ms fp32 conv step;
+  * replicas must stay bit-identical: weights, the spectral-norm ``u`` vectors (random on first use in the reference)
+    and the sampled (K, T, F) are broadcast / derived from rank 0.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (set by torch.distributed.run).
+    Returns (rank, world_size, local_rank); a single un-launched process gets (0, 1, 0) and no group."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_slice(n_items, rank_, world):
+    """Contiguous slice of ``n_items`` clips owned by ``rank_`` (sizes differ by at most one)."""
+    base, rem = divmod(n_items, world)
+    start = rank_ * base + min(rank_, rem)
+    return slice(start, start + base + (1 if rank_ < rem else 0))
+
+
+def broadcast_module_state(module, src=0):
+    """Make every replica's parameters AND buffers (persistent or not, e.g. the SN ``u`` vectors) equal to rank src's."""
+    if world_size() == 1:
+        return
+    for t in list(module.parameters()) + [b for b in module.buffers() if b is not None]:
+        dist.broadcast(t.data, src=src)
+
+
+def materialise_sn_vectors(discriminator):
+    """Draw every spectral-norm ``u`` now (the reference draws it lazily inside the first forward), so that it can be
+    broadcast before the first step."""
+    for m in discriminator.modules():
+        if hasattr(m, 'Ip') and hasattr(m, 'u') and m.u is None:
+            m.u = torch.randn(1, m.weight.size(0), device=m.weight.device, dtype=m.weight.dtype)
+
+
+class GradAllReducer(object):
+    """Averages the gradients of ``params`` across ranks through flat buckets of at most ``bucket_bytes``."""
+
+    def __init__(self, params, bucket_bytes=64 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets, cur, cur_bytes = [], [], 0
+        for p in self.params:
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self.buckets.append(cur)
+
+    def allreduce_(self):
+        world = world_size()
+        if world == 1:
+            return 0
+        total = 0
+        handles = []
+        for bucket in self.buckets:
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
+            total += flat.numel() * flat.element_size()
+        for work, flat, bucket in handles:
+            work.wait()
+            flat.div_(world)
+            off = 0
+            for p in bucket:
+                n = p.numel()
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                p.grad.copy_(flat[off:off + n].view_as(p))
+                off += n
+        return total
+
+
+def allreduce_scalar_mean(value, device):
+    if world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    return float(t.item() / world_size())
