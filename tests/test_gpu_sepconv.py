@@ -98,7 +98,9 @@ def test_box_taps_and_linearity_at_full_size():
         ones = torch.ones_like(v)
         box = vfi.SeparableConvolution.apply(inp, ones, ones, ks)
         ref = torch.nn.functional.avg_pool2d(inp.double(), ks, stride=1) * ks * ks
-        assert float(((box.double() - ref).abs() / (1 + ref.abs())).max()) < FWD_TOL
+        # 2601 O(1) terms that largely cancel: the fp32 bound scales with sum|terms| (~1300 here), not with |ref|
+        mag = torch.nn.functional.avg_pool2d(inp.double().abs(), ks, stride=1) * ks * ks
+        assert float(((box.double() - ref).abs() / mag).max()) < 2e-7
         a = vfi.SeparableConvolution.apply(inp, v, h, ks)
         b = vfi.SeparableConvolution.apply(inp, 2 * v, h, ks)           # linear in v (exact: power-of-two scale)
         assert torch.equal(b, 2 * a)
