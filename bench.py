@@ -37,6 +37,12 @@ from video_frame_inpainting_amd import separable_convolution as sc          # no
 from video_frame_inpainting_amd.graph import GraphedForward                 # noqa: E402
 
 K_, T_, F_, H_, W_, C_ = 5, 5, 5, 128, 128, 1
+_T0 = time.time()
+
+
+def log(msg):
+    print('[bench %7.1fs] %s' % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -71,20 +77,36 @@ def sepconv_roofline(device, B, iters=200, warmup=20):
             'shape': [B, C_, H_, W_], 'us_per_launch': round(us, 2), 'algorithmic_bytes': nbytes}
 
 
-def cpu_baseline_and_parity(model, device, n_clips=2):
+def host_cpu_share(cap=16):
+    """Threads to use on the host: the scheduler affinity, the cgroup CPU quota and the GPU box's per-GPU CPU share (16),
+    whichever is smallest -- oversubscribing a 256-thread host from a 16-core share makes the CPU leg crawl."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline_and_parity(model, device, n_clips=16):
     """Oracle forward on the host cores for a bounded sample (n_clips clips of the workload), and GPU-vs-oracle parity."""
     from oracle import sepconv_oracle, tai_oracle
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cpu_share()
     torch.set_num_threads(cores)
     sepconv_oracle.set_num_threads(cores)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     clips = synthetic.make_clips(n_clips, K_ + T_ + F_, C_, H_, W_, synthetic.SEEDS['cfg1'])
     P, GT, Fo = (torch.from_numpy(x) for x in synthetic.split_clip(clips, K_, T_, F_))
     with torch.no_grad():
+        log('cpu baseline: warm-up forward of the oracle on %d threads' % cores)
         tai_oracle.tai_forward(sd, C_, 5, 51, T_, P[:1], Fo[:1])          # warm-up (thread pools, allocator)
+        log('cpu baseline: timed forward (%d clips)' % n_clips)
         t0 = time.time()
         ref = tai_oracle.tai_forward(sd, C_, 5, 51, T_, P, Fo)
         dt = time.time() - t0
+        log('cpu baseline: %.1f s' % dt)
         out = model(T_, P.to(device), Fo.to(device))
     diff = (out['pred'].cpu() - ref['pred']).abs()
     p_gpu, s_gpu, _ = metrics.compute_errors(out['pred'].cpu().numpy(), GT.numpy())
@@ -114,6 +136,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='clips per GPU (configs[1]: 32)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--miopen-find', action='store_true', help='let MIOpen benchmark its algorithms during warm-up')
     args = ap.parse_args()
 
     rank, world, local_rank = parallel.init_from_env()
@@ -122,10 +145,11 @@ def main():
     _native.lib()                                   # fail loudly if the HIP library is missing
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
-    torch.backends.cudnn.benchmark = True           # MIOpen picks its fastest fp32 algorithm during warm-up
+    torch.backends.cudnn.benchmark = args.miopen_find     # MIOpen exhaustive find is minutes of search: opt-in
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
 
+    log('rank %d/%d on %s' % (rank, world, torch.cuda.get_device_name(device)))
     torch.manual_seed(0)
     model = vfi.create_model('TAI_gray')
     model.apply(vfi.util.weights_init)
@@ -134,12 +158,22 @@ def main():
     clips = synthetic.make_clips(B, K_ + T_ + F_, C_, H_, W_, synthetic.SEEDS['cfg2'] + rank)
     P, _, Fo = (torch.from_numpy(x).to(device) for x in synthetic.split_clip(clips, K_, T_, F_))
 
+    with torch.no_grad():
+        t1 = time.time()
+        model(T_, P, Fo)
+        torch.cuda.synchronize()
+        log('first eager forward (B=%d): %.2f s' % (B, time.time() - t1))
+        t1 = time.time()
+        model(T_, P, Fo)
+        torch.cuda.synchronize()
+        log('second eager forward: %.3f s' % (time.time() - t1))
     if args.no_graph:
         def step():
             with torch.no_grad():
                 return model(T_, P, Fo)
     else:
-        graphed = GraphedForward(model, T_, P, Fo, warmup=2)
+        graphed = GraphedForward(model, T_, P, Fo, warmup=1)
+        log('hipGraph captured')
         step = lambda: graphed()
 
     def fence():
@@ -150,11 +184,13 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    log('warm-up done')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    log('timed %d steps: %.3f s' % (args.steps, dt))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -175,6 +211,7 @@ def main():
     }
     if rank == 0:
         line['roofline'] = sepconv_roofline(device, B)
+        log('roofline measured')
         if world == 1 and not args.no_cpu_baseline:
             base, parity = cpu_baseline_and_parity(model, device)
             line['cpu_baseline'] = base

@@ -55,6 +55,12 @@ int tai_sepconv_backward(const float* grad_output, const float* input, const flo
                          float* grad_horizontal, int B, int C, int H, int W, int ks,
                          void* hip_stream);
 
+/* Bilinear x2 upsampling, align_corners = true, fp32 NCHW with planes = N*C: output [planes, 2H, 2W].
+ * Replaces the THCUNN kernel behind the reference's torch.nn.Upsample(scale_factor=2, mode='bilinear') calls
+ * (src/models/tai/tai.py:283,337,343; torch 0.3.1 semantics = align_corners=True), same caller-allocates / asynchronous-
+ * on-stream conventions as above. */
+int tai_upsample_bilinear2x_forward(const float* input, float* output, int planes, int H, int W, void* hip_stream);
+
 /* Selects a kernel variant for tai_sepconv_forward (benchmarking / tests):
  *   0 = automatic (default), 1 = generic one-thread-per-output kernel (any shape),
  *   2 = LDS-tiled, whole tap set register-resident, 3 = LDS-tiled, taps split over half-waves,

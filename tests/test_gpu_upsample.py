@@ -1,0 +1,28 @@
+"""The HIP bilinear x2 upsample (align_corners=True) against ATen on CPU (the oracle's arithmetic) and on GPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from video_frame_inpainting_amd.upsample import upsample2x
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 5, 6), (1, 1, 1, 2), (2, 51, 64, 64), (1, 65, 16, 16), (3, 2, 7, 1), (1, 4, 4, 3)])
+def test_matches_aten(shape):
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(1))
+    want = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+    got = upsample2x(x.cuda())
+    assert got.shape == want.shape
+    assert float((got.cpu() - want).abs().max()) <= 2e-6
+    aten_gpu = F.interpolate(x.cuda(), scale_factor=2, mode='bilinear', align_corners=True)
+    assert float((got - aten_gpu).abs().max()) <= 2e-6
+
+
+def test_backward_matches_aten():
+    x = torch.randn(2, 3, 6, 8, generator=torch.Generator().manual_seed(2)).cuda().requires_grad_()
+    g = torch.randn(2, 3, 12, 16, generator=torch.Generator().manual_seed(3)).cuda()
+    upsample2x(x).backward(g)
+    x2 = x.detach().clone().requires_grad_()
+    F.interpolate(x2, scale_factor=2, mode='bilinear', align_corners=True).backward(g)
+    assert float((x.grad - x2.grad).abs().max()) <= 1e-5

@@ -13,6 +13,7 @@
 
 #include "sepconv_fwd.hip.inc"
 #include "sepconv_bwd.hip.inc"
+#include "upsample.hip.inc"
 
 namespace {
 
@@ -195,6 +196,28 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 102: return fwd_asm_all_channels<false, 2>(input, vertical, horizontal, output, B, C, H, W, s);
         default: return fail(TAI_SEPCONV_EINVAL, "%s", "unknown forward variant");
     }
+}
+
+int tai_upsample_bilinear2x_forward(const float* input, float* output, int planes, int H, int W, void* hip_stream) {
+    g_err[0] = 0;
+    if (!input || !output) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (planes <= 0 || H <= 0 || W <= 0) return fail(TAI_SEPCONV_EINVAL, "%s", "bad dimensions");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    // ATen's area_pixel_compute_scale for align_corners = true, in fp32
+    const float rh = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
+    const float rw = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
+    const long long total = (long long)planes * 2 * H * (2 * W);
+    if ((2 * W) % 4 == 0) {
+        const long long threads = total / 4;
+        const int blocks = (int)((threads + 255) / 256 < 65536 ? (threads + 255) / 256 : 65536);
+        hipLaunchKernelGGL(ups::upsample2x_align_corners_quads, dim3(blocks), dim3(256), 0, s, input, output, planes, H,
+                           W, rh, rw);
+    } else {
+        const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+        hipLaunchKernelGGL(ups::upsample2x_align_corners_scalar, dim3(blocks), dim3(256), 0, s, input, output, planes,
+                           H, W, rh, rw);
+    }
+    return check_launch("upsample2x_align_corners");
 }
 
 int tai_sepconv_backward(const float* grad_output, const float* input, const float* vertical,

@@ -16,7 +16,8 @@ What is arranged differently from the reference (same arithmetic):
   * the time ratio enters as a constant extra channel only where the reference injects it (decoder block 3 of the
     5-block gray model; the 4-block colour model never reaches that index, tai.py:213-217), built on the input's
     device without a host round trip;
-  * torch 0.3.1's bilinear upsample is what modern PyTorch calls ``align_corners=True``;
+  * torch 0.3.1's bilinear upsample is what modern PyTorch calls ``align_corners=True``; it runs on its own HIP
+    kernel (upsample.py): the stock ATen kernel was 25 % of the forward on MI355X;
   * the separable convolutions call the HIP kernels through the C ABI (separable_convolution.py) on the current
     stream: the whole forward is hipGraph-capturable (graph.py).
 """
@@ -29,11 +30,12 @@ import torch.nn.functional as F
 
 from .mcnet import IndexedConvs, MCNet, Residual, _conv_relu_chain
 from .separable_convolution import SeparableConvolution
+from .upsample import upsample2x
 from .util import gray01
 
 
 def _up2(x):
-    return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+    return upsample2x(x)
 
 
 def create_basic_conv_block(num_layers, num_in_channels, num_out_channels):
