@@ -14,7 +14,8 @@ def test_matches_aten(shape):
     want = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
     got = upsample2x(x.cuda())
     assert got.shape == want.shape
-    assert float((got.cpu() - want).abs().max()) <= 2e-6
+    # the CPU kernel rounds the fp32 source coordinate differently: weights differ by ~4e-6 at 64 -> 128
+    assert float((got.cpu() - want).abs().max()) <= 5e-5
     aten_gpu = F.interpolate(x.cuda(), scale_factor=2, mode='bilinear', align_corners=True)
     assert float((got - aten_gpu).abs().max()) <= 2e-6
 
