@@ -66,7 +66,10 @@ int tai_upsample_bilinear2x_forward(const float* input, float* output, int plane
  *   2 = LDS-tiled, whole tap set register-resident, 3 = LDS-tiled, taps split over half-waves,
  *   4 = LDS-tiled, register-resident taps, packed fp32 FMAs (v_pk_fma_f32),
  *   5 = as 4 with the row loop hand-scheduled in gfx950 assembly (v planes by LDS-DMA), 6 = as 5 with
- *       the tap loads of half the waves deferred behind a workgroup barrier.
+ *       the tap loads of half the waves deferred behind a workgroup barrier, 7-9 = 16-row tiles (8 waves),
+ *   10-13 = 8-wave workgroups mixing "taps first" (type A) and "taps last" (type B) waves on every SIMD;
+ *       13 (default for C == 1) adds 16-byte patch staging and alternating wave priorities.
+ *   Values >= 100 are timing experiments and may produce wrong results.
  * Returns the previous value. */
 int tai_sepconv_set_forward_variant(int variant);
 

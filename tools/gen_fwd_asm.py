@@ -31,14 +31,18 @@ PITCH_BYTES = 180 * 4
 RING = 7                 # v rows in flight
 SLOTS = RING + 1         # ring slots (power of two)
 LOOKAHEAD = 3            # window chunks in flight ahead of the one being consumed
+NBUF = 4                 # window buffers (LOOKAHEAD + 1)
+ABLATE_VMCNT = False     # timing experiments only: drop the v-ring wait / the window waits (results are then wrong)
+ABLATE_LGKM = False
+PRIO_ALTERNATE = False   # type A: s_setprio 2 on even rows, 0 on odd rows (its type-B SIMD partner sits at 1)
 NCHUNK = 14              # 13 x b128 + 1 x b64 = 27 window pairs
 NW2 = 27
 
 A = lambda p, t: 51 * p + t
 ACC = lambda p: 204 + 2 * p
 O = lambda p: 212 + 2 * p
-BUF = lambda k: 220 + 4 * (k % 4)   # k = running chunk number (14 per row: the rotation shifts by 2 per row)
-VV = 236
+BUF = lambda k: 220 + 4 * (k % NBUF)   # k = running chunk number (14 per row: the rotation shifts per row)
+VV = 244              # v values of the row: v[244:247]
 V_ROW, V_RING, V_GOFF, V_TMP = 240, 241, 242, 243
 
 # scalar registers (all named explicitly and listed as clobbers, except the inputs)
@@ -111,7 +115,10 @@ def emit_chunk_fmas(lines, k, first_done, base=0):
 
 def emit_row(L, phase):
     base = NCHUNK * phase            # running chunk number of this row's chunk 0
-    L.append('s_waitcnt vmcnt(%d)' % (RING - 1))
+    if PRIO_ALTERNATE:
+        L.append('s_setprio %d' % (2 if phase % 2 == 0 else 0))
+    if not ABLATE_VMCNT:
+        L.append('s_waitcnt vmcnt(%d)' % (RING - 1))
     L.append('v_add_u32 v%d, %s, v%d' % (V_TMP, S_SLOT_RD, V_RING))
     L.append('ds_read_b128 v[%d:%d], v%d' % (VV, VV + 3, V_TMP))
     # DMA of row fy + RING (source pointer stops advancing at the last row: the tail re-fetches row ks-1)
@@ -135,7 +142,7 @@ def emit_row(L, phase):
         else:
             emit_chunk_read(L, nk - NCHUNK, PITCH_BYTES, base + NCHUNK)
         # outstanding LDS ops after this issue, oldest first: chunk k, k+1, k+2, (v row if k < 3), chunk k+3
-        L.append('s_waitcnt lgkmcnt(%d)' % (LOOKAHEAD + (1 if k < LOOKAHEAD else 0)))
+        L.append('s_waitcnt lgkmcnt(%d)' % (15 if ABLATE_LGKM else LOOKAHEAD + (1 if k < LOOKAHEAD else 0)))
         emit_chunk_fmas(L, k, first_done, base)
     # fold with v:  O_p += (v_p, v_p) * ACC_p
     L.append('v_pk_fma_f32 %s, %s, %s, %s op_sel_hi:[0,1,1]' % (pair(O(0)), pair(VV), pair(ACC(0)), pair(O(0))))
@@ -171,33 +178,159 @@ def gen():
     L.append('1:')
     # 14 chunks per row over 4 buffers: the rotation shifts by 2 per row, so the loop body is TWO rows
     # (phase 0 and phase 1) and the odd 51st row is emitted once more behind the loop.
-    emit_row(L, 0)
-    emit_row(L, 1)
-    L.append('s_cmp_lt_u32 %s, %d' % (S_ROW, KS - 1))
+    from math import gcd
+    period = NBUF // gcd(NCHUNK, NBUF)          # rows after which the buffer rotation repeats
+    body_rows = period
+    n_loops = KS // body_rows
+    for ph in range(body_rows):
+        emit_row(L, ph)
+    L.append('s_cmp_lt_u32 %s, %d' % (S_ROW, n_loops * body_rows))
     L.append('s_cbranch_scc1 1b')
-    emit_row(L, 0)
+    for ph in range(KS - n_loops * body_rows):
+        emit_row(L, ph)
     # ---------------- drain: the three window reads issued for the (non-existent) next row, the DMA tail
     L.append('s_waitcnt vmcnt(0) lgkmcnt(0)')
+    if PRIO_ALTERNATE:
+        L.append('s_setprio 0')
+    return L
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Type B row loop ("taps last"): the lane keeps ks x 4 ACCUMULATORS c_p[fx] = sum_fy v_p[fy] * in[y+fy, x+p+fx]
+# register-resident (same register layout as the taps: c_p[t] in v[51p + t]), streams v one plane per row exactly like
+# type A, and has NO per-row fold: 100 v_pk_fma_f32 + 4 v_fmac_f32 per row.  The taps are needed only after the loop
+# (out_p = sum_fx h_p[fx] * c_p[fx], done in HIP C++), so a type-B wave starts its FMAs at once and streams h at the END
+# of its life, while a type-A wave streams h at the START: one of each per SIMD keeps both HBM and the VALU busy.
+VVB = (244, 236)         # v values of the current row alternate between v[244:247] and v[236:239]
+
+
+def emit_chunk_fmas_b(lines, k, base, vv):
+    for hh in range(2):
+        m = 2 * k + hh
+        if m >= NW2:
+            continue
+        w = BUF(base + k) + 2 * hh
+        for p in range(4):
+            i = m - (p >> 1)
+            if i < 0 or i > 25:
+                continue
+            vp = vv + 2 * (p >> 1)                      # register pair holding v_p
+            sel = 'op_sel_hi:[0,1,1]' if p % 2 == 0 else 'op_sel:[1,0,0] op_sel_hi:[1,1,1]'
+            if p % 2 == 0:
+                if i <= 24:
+                    c = A(p, 2 * i)
+                    lines.append('v_pk_fma_f32 %s, %s, %s, %s %s' % (pair(c), pair(vp), pair(w), pair(c), sel))
+                else:
+                    lines.append('v_fmac_f32 v%d, v%d, v%d' % (A(p, 50), vp, w))               # c50 += v_p * W.lo
+            else:
+                if i == 0:
+                    lines.append('v_fmac_f32 v%d, v%d, v%d' % (A(p, 0), vp + 1, w + 1))        # c0 += v_p * W.hi
+                else:
+                    c = A(p, 2 * i - 1)
+                    lines.append('v_pk_fma_f32 %s, %s, %s, %s %s' % (pair(c), pair(vp), pair(w), pair(c), sel))
+
+
+def emit_row_b(L, phase):
+    base = NCHUNK * phase
+    vv_cur, vv_next = VVB[phase % 2], VVB[(phase + 1) % 2]
+    L.append('s_waitcnt vmcnt(%d)' % (RING - 2))                      # row fy+1 of v has landed in the ring
+    L.append('v_add_u32 v%d, %s, v%d' % (V_TMP, S_SLOT_RD, V_RING))   # S_SLOT_RD = slot of row fy+1
+    L.append('ds_read_b128 v[%d:%d], v%d' % (vv_next, vv_next + 3, V_TMP))
+    L.append('s_add_u32 %s, %s, %s' % (S_T0, S_RINGM0, S_SLOT_WR))
+    L.append('s_mov_b32 m0, %s' % S_T0)
+    L.append('s_nop 0')
+    L.append('global_load_lds_dwordx4 v%d, s[64:65]' % V_GOFF)
+    L.append('s_cmp_lt_u32 %s, %d' % (S_ROW, KS - 1 - RING))
+    L.append('s_cselect_b32 %s, %s, 0' % (S_T1, S_PLANE))
+    L.append('s_add_u32 %s, %s, %s' % (S_PTR_LO, S_PTR_LO, S_T1))
+    L.append('s_addc_u32 %s, %s, 0' % (S_PTR_HI, S_PTR_HI))
+    L.append('s_add_u32 %s, %s, 1024' % (S_SLOT_RD, S_SLOT_RD))
+    L.append('s_and_b32 %s, %s, %d' % (S_SLOT_RD, S_SLOT_RD, SLOTS * 1024 - 1))
+    L.append('s_add_u32 %s, %s, 1024' % (S_SLOT_WR, S_SLOT_WR))
+    L.append('s_and_b32 %s, %s, %d' % (S_SLOT_WR, S_SLOT_WR, SLOTS * 1024 - 1))
+    for k in range(NCHUNK):
+        nk = k + LOOKAHEAD
+        if nk < NCHUNK:
+            emit_chunk_read(L, nk, 0, base)
+        else:
+            emit_chunk_read(L, nk - NCHUNK, PITCH_BYTES, base + NCHUNK)
+        L.append('s_waitcnt lgkmcnt(%d)' % (LOOKAHEAD + (1 if k < LOOKAHEAD else 0)))
+        emit_chunk_fmas_b(L, k, base, vv_cur)
+    L.append('v_add_u32 v%d, %d, v%d' % (V_ROW, PITCH_BYTES, V_ROW))
+    L.append('s_add_u32 %s, %s, 1' % (S_ROW, S_ROW))
+
+
+def gen_b():
+    L = []
+    for r in range(0, 204, 2):
+        L.append('v_mov_b64 v[%d:%d], 0' % (r, r + 1))
+    L.append('s_mov_b32 %s, s60' % S_PTR_LO)
+    L.append('s_mov_b32 %s, s61' % S_PTR_HI)
+    for r in range(RING):
+        L.append('s_add_u32 %s, %s, %d' % (S_T0, S_RINGM0, r * 1024))
+        L.append('s_mov_b32 m0, %s' % S_T0)
+        L.append('s_nop 0')
+        L.append('global_load_lds_dwordx4 v%d, s[64:65]' % V_GOFF)
+        L.append('s_add_u32 %s, %s, %s' % (S_PTR_LO, S_PTR_LO, S_PLANE))
+        L.append('s_addc_u32 %s, %s, 0' % (S_PTR_HI, S_PTR_HI))
+    L.append('s_mov_b32 %s, 0' % S_ROW)
+    L.append('s_setprio 1')
+    L.append('s_mov_b32 %s, 1024' % S_SLOT_RD)                         # the in-loop read fetches row fy+1
+    L.append('s_mov_b32 %s, %d' % (S_SLOT_WR, RING * 1024))
+    L.append('s_waitcnt vmcnt(%d)' % (RING - 1))                       # row 0 has landed
+    L.append('ds_read_b128 v[%d:%d], v%d' % (VVB[0], VVB[0] + 3, V_RING))
+    for k in range(LOOKAHEAD):
+        emit_chunk_read(L, k, 0)
+    L.append('.p2align 6')
+    L.append('1:')
+    assert NBUF == 4 and NCHUNK == 14
+    emit_row_b(L, 0)
+    emit_row_b(L, 1)
+    L.append('s_cmp_lt_u32 %s, %d' % (S_ROW, KS - 1))
+    L.append('s_cbranch_scc1 1b')
+    emit_row_b(L, 0)
+    L.append('s_waitcnt vmcnt(0) lgkmcnt(0)')
+    L.append('s_setprio 0')
     return L
 
 
 def main():
-    lines = gen()
-    n_pk = sum(1 for l in lines if l.startswith('v_pk_'))
+    global LOOKAHEAD, NBUF, ABLATE_VMCNT, ABLATE_LGKM, PRIO_ALTERNATE
     here = os.path.dirname(os.path.abspath(__file__))
     out = os.path.join(here, '..', 'video-frame-inpainting_amd', 'csrc', 'sepconv_fwd_rowloop.inc')
+    variants = [('TAI_FWD_ROWLOOP_ASM', 3, 4, False, False),
+                ('TAI_FWD_ROWLOOP_ASM_LA4', 4, 5, False, False),          # 4 chunks ahead, 5 buffers (v[220:239])
+                ('TAI_FWD_ROWLOOP_ASM_NOVM', 3, 4, True, False),          # timing experiment: no v-ring wait
+                ('TAI_FWD_ROWLOOP_ASM_NOLGKM', 3, 4, False, True)]        # timing experiment: no window waits
     with open(out, 'w') as f:
         f.write('// GENERATED by tools/gen_fwd_asm.py -- do not edit.  Register map and schedule: see the generator.\n')
-        f.write('// ks=%d ring=%d slots=%d lookahead=%d; %d instructions, %d packed.\n' % (KS, RING, SLOTS, LOOKAHEAD, len(lines), n_pk))
         f.write('#define TAI_FWD_ROWLOOP_RING_SLOTS %d\n' % SLOTS)
-        f.write('#define TAI_FWD_ROWLOOP_ASM \\\n')
+        variants.append(('TAI_FWD_ROWLOOP_ASM_PRIO', 3, 4, False, False))   # type A next to a type-B partner
+        for name, la, nbuf, novm, nolgkm in variants:
+            LOOKAHEAD, NBUF, ABLATE_VMCNT, ABLATE_LGKM = la, nbuf, novm, nolgkm
+            PRIO_ALTERNATE = name.endswith('_PRIO')
+            lines = gen()
+            n_pk = sum(1 for l in lines if l.startswith('v_pk_'))
+            f.write('// %s: ks=%d ring=%d slots=%d lookahead=%d buffers=%d; %d instructions, %d packed.\n'
+                    % (name, KS, RING, SLOTS, LOOKAHEAD, NBUF, len(lines), n_pk))
+            f.write('#define %s \\\n' % name)
+            for l in lines:
+                f.write('    "%s\\n" \\\n' % l)
+            f.write('    ""\n')
+        LOOKAHEAD, NBUF, ABLATE_VMCNT, ABLATE_LGKM, PRIO_ALTERNATE = 3, 4, False, False, False
+        lines = gen_b()
+        f.write('// TAI_FWD_ROWLOOP_B_ASM (accumulators resident, taps last): %d instructions.\n' % len(lines))
+        f.write('#define TAI_FWD_ROWLOOP_B_ASM \\\n')
         for l in lines:
             f.write('    "%s\\n" \\\n' % l)
         f.write('    ""\n')
-        clob = ['v%d' % r for r in list(range(204, 212)) + list(range(220, 240)) + [243]]
+        clob_b = ['v%d' % r for r in list(range(220, 240)) + [243, 244, 245, 246, 247]]
+        clob_b += ['s%d' % r for r in range(64, 71)] + ['scc', 'memory']
+        f.write('#define TAI_FWD_ROWLOOP_B_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob_b))
+        clob = ['v%d' % r for r in list(range(204, 212)) + list(range(220, 240)) + [243, 244, 245, 246, 247]]
         clob += ['s%d' % r for r in range(64, 71)] + ['scc', 'memory']   # m0 is written too; hipcc reloads it before each of its own uses
         f.write('#define TAI_FWD_ROWLOOP_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob))
-    print('wrote %s: %d lines' % (out, len(lines)))
+    print('wrote %s' % out)
 
 
 if __name__ == '__main__':

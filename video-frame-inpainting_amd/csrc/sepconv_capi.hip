@@ -81,19 +81,37 @@ int launch_fwd_packed(const float* in, const float* v, const float* h, float* ou
     return check_launch("sepconv_forward_packed");
 }
 
-template <bool STAGGER, int DBG = 0>
+template <bool STAGGER, int DBG = 0, int WAVES = 4, int ASMV = 0>
 int fwd_asm_all_channels(const float* in, const float* v, const float* h, float* out, int B, int C, int H,
                          int W, hipStream_t s) {
-    using K = fwd::Cfg<51, 1>;
+    constexpr int TILE_H = 2 * WAVES;
     const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W;
-    const int tiles_y = (H + K::TILE_H - 1) / K::TILE_H;
-    const size_t lds = ((K::lds_bytes(1) + 1023) & ~(size_t)1023) + 4 * TAI_FWD_ROWLOOP_RING_SLOTS * 1024;
-    auto kern = fwd::sepconv_forward_asm<STAGGER, DBG>;
+    const int tiles_y = (H + TILE_H - 1) / TILE_H;
+    const size_t patch = (size_t)(TILE_H + 50) * 180 * sizeof(float);
+    const size_t lds = ((patch + 1023) & ~(size_t)1023) + (size_t)WAVES * TAI_FWD_ROWLOOP_RING_SLOTS * 1024;
+    auto kern = fwd::sepconv_forward_asm<STAGGER, DBG, WAVES, ASMV>;
     if (int rc = allow_lds(kern, lds)) return rc;
     for (int c0 = 0; c0 < C; ++c0) {
-        hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(K::THREADS), lds, s, in, v, h, out, C, c0,
-                           H, W, tiles_x, tiles_y);
+        hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(WAVES * 64), lds, s, in, v, h, out, C, c0, H, W,
+                           tiles_x, tiles_y);
         if (int rc = check_launch("sepconv_forward_asm")) return rc;
+    }
+    return TAI_SEPCONV_OK;
+}
+
+template <int MIXMODE, int DBG = 0>
+int fwd_ab_all_channels(const float* in, const float* v, const float* h, float* out, int B, int C, int H, int W,
+                        hipStream_t s) {
+    const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W;
+    const int tiles_y = (H + 15) / 16;
+    const size_t patch = (size_t)(16 + 50) * 180 * sizeof(float);
+    const size_t lds = ((patch + 1023) & ~(size_t)1023) + (size_t)8 * TAI_FWD_ROWLOOP_RING_SLOTS * 1024;
+    auto kern = fwd::sepconv_forward_ab<MIXMODE, DBG>;
+    if (int rc = allow_lds(kern, lds)) return rc;
+    for (int c0 = 0; c0 < C; ++c0) {
+        hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(512), lds, s, in, v, h, out, C, c0, H, W, tiles_x,
+                           tiles_y);
+        if (int rc = check_launch("sepconv_forward_ab")) return rc;
     }
     return TAI_SEPCONV_OK;
 }
@@ -176,8 +194,8 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
 
     int variant = g_fwd_variant;
     const bool tileable = (ks == 51) && (W % 4 == 0);
-    // default: hand-scheduled packed kernel for single-channel frames, half-wave tap split for RGB
-    if (variant == 0) variant = !tileable ? 1 : (C == 1 ? 5 : 3);
+    // default: mixed type-A / type-B hand-scheduled kernel for single-channel frames, half-wave tap split for RGB
+    if (variant == 0) variant = !tileable ? 1 : (C == 1 ? 13 : 3);
     if (variant != 1 && !tileable)
         return fail(TAI_SEPCONV_EINVAL, "%s", "tiled forward variants need ks == 51 and W % 4 == 0");
     switch (variant) {
@@ -192,6 +210,21 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 4: return fwd_packed_all_channels<51>(input, vertical, horizontal, output, B, C, H, W, s);
         case 5: return fwd_asm_all_channels<false>(input, vertical, horizontal, output, B, C, H, W, s);
         case 6: return fwd_asm_all_channels<true>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 7: return fwd_asm_all_channels<false, 0, 8>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 8: return fwd_asm_all_channels<true, 0, 8>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 9: return fwd_asm_all_channels<false, 0, 8, 1>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 10: return fwd_ab_all_channels<0>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 11: return fwd_ab_all_channels<1>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 12: return fwd_ab_all_channels<2>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 13: return fwd_ab_all_channels<3>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 108: return fwd_ab_all_channels<3, 3>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 106: return fwd_ab_all_channels<0, 3>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 107: return fwd_ab_all_channels<2, 3>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 111: return fwd_asm_all_channels<false, 0, 8, 2>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 112: return fwd_asm_all_channels<false, 0, 8, 3>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 103: return fwd_asm_all_channels<false, 3, 8>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 104: return fwd_asm_all_channels<true, 3, 8>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 105: return fwd_asm_all_channels<false, 3, 4>(input, vertical, horizontal, output, B, C, H, W, s);
         case 101: return fwd_asm_all_channels<false, 1>(input, vertical, horizontal, output, B, C, H, W, s);
         case 102: return fwd_asm_all_channels<false, 2>(input, vertical, horizontal, output, B, C, H, W, s);
         default: return fail(TAI_SEPCONV_EINVAL, "%s", "unknown forward variant");
