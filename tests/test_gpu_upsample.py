@@ -12,12 +12,14 @@ pytestmark = pytest.mark.gpu
 def test_matches_aten(shape):
     x = torch.randn(*shape, generator=torch.Generator().manual_seed(1))
     want = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+    exact = F.interpolate(x.double(), scale_factor=2, mode='bilinear', align_corners=True)
     got = upsample2x(x.cuda())
     assert got.shape == want.shape
-    # the CPU kernel rounds the fp32 source coordinate differently: weights differ by ~4e-6 at 64 -> 128
+    # against the exact (fp64) interpolation: fp32 rounding of the source coordinate and of the 2x2 blend
+    assert float((got.cpu().double() - exact).abs().max()) <= 5e-6
+    # ATen's fp32 kernels (CPU and GPU agree bit for bit) sit 1.4e-5 from the exact result at 64 -> 128 (measured on
+    # MI355X, tools/up_probe.py); this kernel is 2.4e-6 from it, so the two differ by up to ~1.4e-5
     assert float((got.cpu() - want).abs().max()) <= 5e-5
-    aten_gpu = F.interpolate(x.cuda(), scale_factor=2, mode='bilinear', align_corners=True)
-    assert float((got - aten_gpu).abs().max()) <= 2e-6
 
 
 def test_backward_matches_aten():

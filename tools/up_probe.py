@@ -1,0 +1,13 @@
+import sys; sys.path.insert(0, '.')
+import torch, torch.nn.functional as F
+from video_frame_inpainting_amd.upsample import upsample2x
+x = torch.randn(2, 51, 64, 64, generator=torch.Generator().manual_seed(1))
+cpu = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+ref = F.interpolate(x.double(), scale_factor=2, mode='bilinear', align_corners=True)
+gpu = F.interpolate(x.cuda(), scale_factor=2, mode='bilinear', align_corners=True).cpu()
+mine = upsample2x(x.cuda()).cpu()
+f = lambda a, b: float((a.double() - b.double()).abs().max())
+print('cpu-vs-f64', f(cpu, ref), 'gpu-vs-f64', f(gpu, ref), 'mine-vs-f64', f(mine, ref))
+print('cpu-vs-gpu', f(cpu, gpu), 'mine-vs-cpu', f(mine, cpu), 'mine-vs-gpu', f(mine, gpu))
+d = (mine.double() - gpu.double()).abs()
+i = int(d.argmax()); print('argmax idx', i, 'oy', (i // 128) % 128, 'ox', i % 128)
