@@ -116,7 +116,8 @@ def emit_chunk_fmas(lines, k, first_done, base=0):
 def emit_row(L, phase):
     base = NCHUNK * phase            # running chunk number of this row's chunk 0
     if PRIO_ALTERNATE:
-        L.append('s_setprio %d' % (2 if phase % 2 == 0 else 0))
+        # the type-B partner sits at priority 1: this wave wins the SIMD's VALU arbitration on 2 rows out of 3
+        L.append('s_setprio %d' % (0 if phase % 3 == 2 else 2))
     if not ABLATE_VMCNT:
         L.append('s_waitcnt vmcnt(%d)' % (RING - 1))
     L.append('v_add_u32 v%d, %s, v%d' % (V_TMP, S_SLOT_RD, V_RING))
@@ -180,7 +181,7 @@ def gen():
     # (phase 0 and phase 1) and the odd 51st row is emitted once more behind the loop.
     from math import gcd
     period = NBUF // gcd(NCHUNK, NBUF)          # rows after which the buffer rotation repeats
-    body_rows = period
+    body_rows = period * 3 if PRIO_ALTERNATE else period
     n_loops = KS // body_rows
     for ph in range(body_rows):
         emit_row(L, ph)
