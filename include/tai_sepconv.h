@@ -61,6 +61,11 @@ int tai_sepconv_backward(const float* grad_output, const float* input, const flo
  * on-stream conventions as above. */
 int tai_upsample_bilinear2x_forward(const float* input, float* output, int planes, int H, int W, void* hip_stream);
 
+/* In-place x[n,c,:] = act(x[n,c,:] + bias[c]) over a contiguous fp32 [N, C, HW] tensor; act: 0 none, 1 ReLU, 2 tanh.
+ * Finishes the bias-free MIOpen convolutions of the generator in one pass (the reference's nn.Conv2d + nn.ReLU / nn.Tanh
+ * pairs, src/models/mcnet/mcnet.py:28-43,79-102,137-144,172-176,203-225; src/models/tai/tai.py:256-261). */
+int tai_bias_act_inplace(float* x, const float* bias, int N, int C, int HW, int act, void* hip_stream);
+
 /* Selects a kernel variant for tai_sepconv_forward (benchmarking / tests):
  *   0 = automatic (default), 1 = generic one-thread-per-output kernel (any shape),
  *   2 = LDS-tiled, whole tap set register-resident, 3 = LDS-tiled, taps split over half-waves,

@@ -1,0 +1,36 @@
+"""Convolution + bias + activation as the generator uses it (reference: nn.Conv2d / nn.ConvTranspose2d followed by
+nn.ReLU, nn.Tanh or nothing).  Inference on the GPU runs the bias-free MIOpen convolution and finishes it with the
+single-pass HIP bias+activation kernel of the C ABI (ATen would add the bias and apply the ReLU in two more full passes);
+anything that needs autograd, and CPU tensors, take the stock PyTorch ops -- same arithmetic, one rounding per add."""
+import torch
+import torch.nn.functional as F
+
+from . import _native
+
+_ACT = {None: 0, 'relu': 1, 'tanh': 2}
+
+
+def _finish(y, bias, act):
+    if act == 'relu':
+        return torch.relu(y + bias.view(1, -1, 1, 1)) if bias is not None else torch.relu(y)
+    if act == 'tanh':
+        return torch.tanh(y + bias.view(1, -1, 1, 1)) if bias is not None else torch.tanh(y)
+    return y + bias.view(1, -1, 1, 1) if bias is not None else y
+
+
+def conv_bias_act(x, weight, bias, padding, act):
+    """act(conv2d(x, weight, stride 1, padding) + bias), act in {None, 'relu', 'tanh'}."""
+    fused = (x.is_cuda and x.dtype == torch.float32 and bias is not None
+             and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or bias.requires_grad)))
+    if not fused:
+        y = F.conv2d(x, weight, bias, stride=1, padding=padding)
+        return torch.relu(y) if act == 'relu' else (torch.tanh(y) if act == 'tanh' else y)
+    y = F.conv2d(x, weight, None, stride=1, padding=padding)
+    if not y.is_contiguous():
+        y = y.contiguous()
+    N, C, H, W = y.shape
+    with torch.cuda.device(y.device):
+        _native.check(_native.lib().tai_bias_act_inplace(y.data_ptr(), bias.data_ptr(), N, C, H * W, _ACT[act],
+                                                         torch.cuda.current_stream(y.device).cuda_stream),
+                      'tai_bias_act_inplace')
+    return y

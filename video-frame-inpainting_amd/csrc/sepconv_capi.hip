@@ -6,6 +6,7 @@
 // allocation or copy on any path, so every call can be captured into a hipGraph.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 
@@ -14,6 +15,7 @@
 #include "sepconv_fwd.hip.inc"
 #include "sepconv_bwd.hip.inc"
 #include "upsample.hip.inc"
+#include "bias_act.hip.inc"
 
 namespace {
 
@@ -229,6 +231,25 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 102: return fwd_asm_all_channels<false, 2>(input, vertical, horizontal, output, B, C, H, W, s);
         default: return fail(TAI_SEPCONV_EINVAL, "%s", "unknown forward variant");
     }
+}
+
+int tai_bias_act_inplace(float* x, const float* bias, int N, int C, int HW, int act, void* hip_stream) {
+    g_err[0] = 0;
+    if (!x || !bias) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return fail(TAI_SEPCONV_EINVAL, "%s", "bad dimensions or activation");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const long long n = (long long)N * C * HW;
+    const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const long long work = vec ? n / 4 : n;
+    const int blocks = (int)((work + 255) / 256 < 16384 ? (work + 255) / 256 : 16384);
+#define TAI_LAUNCH_BACT(A)                                                                                        \
+    if (vec) hipLaunchKernelGGL(bact::bias_act_vec4<A>, dim3(blocks), dim3(256), 0, s, x, bias, n / 4, HW / 4, C); \
+    else hipLaunchKernelGGL(bact::bias_act_scalar<A>, dim3(blocks), dim3(256), 0, s, x, bias, n, HW, C)
+    if (act == bact::ACT_RELU) { TAI_LAUNCH_BACT(bact::ACT_RELU); }
+    else if (act == bact::ACT_TANH) { TAI_LAUNCH_BACT(bact::ACT_TANH); }
+    else { TAI_LAUNCH_BACT(bact::ACT_NONE); }
+#undef TAI_LAUNCH_BACT
+    return check_launch("bias_act");
 }
 
 int tai_upsample_bilinear2x_forward(const float* input, float* output, int planes, int H, int W, void* hip_stream) {

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .conv_ops import conv_bias_act
 from .util import gray01
 
 
@@ -38,19 +39,17 @@ class IndexedConvs(nn.Module):
 
 
 def _conv_relu_chain(x, convs, last_act='relu'):
+    """conv + bias + ReLU for every layer but the last, which gets ``last_act`` ('relu', 'tanh' or None)."""
     for i, c in enumerate(convs):
-        x = c(x)
-        if i + 1 < len(convs) or last_act == 'relu':
-            x = torch.relu_(x) if not x.requires_grad else torch.relu(x)
-        elif last_act == 'tanh':
-            x = torch.tanh(x)
+        act = 'relu' if i + 1 < len(convs) else last_act
+        x = conv_bias_act(x, c.weight, c.bias, c.padding[0], act)
     return x
 
 
-def _convt3x3_as_conv(x, layer):
+def _convt3x3_as_conv(x, layer, act):
     # ConvTranspose2d(cin, cout, 3, stride 1, padding 1)  ==  conv2d with weight[o, i, ky, kx] = wt[i, o, 2-ky, 2-kx]
     w = layer.weight.transpose(0, 1).flip(2, 3)
-    return F.conv2d(x, w, layer.bias, stride=1, padding=1)
+    return conv_bias_act(x, w, layer.bias, 1, act)
 
 
 def unpool2x_add(x, res):
@@ -132,8 +131,7 @@ class DecCnn(nn.Module):
     @staticmethod
     def _stage(x, layers, last_act):
         for i, layer in enumerate(layers):
-            x = _convt3x3_as_conv(x, layer)
-            x = torch.tanh(x) if (last_act == 'tanh' and i + 1 == len(layers)) else torch.relu(x)
+            x = _convt3x3_as_conv(x, layer, 'tanh' if (last_act == 'tanh' and i + 1 == len(layers)) else 'relu')
         return x
 
     def forward(self, comb, res1, res2, res3):
@@ -157,7 +155,7 @@ class ConvLstmCell(nn.Module):
 
     def forward(self, input, state):
         c, h = torch.chunk(state, 2, dim=1)
-        gates = self.conv(torch.cat((input, h), dim=1))
+        gates = conv_bias_act(torch.cat((input, h), dim=1), self.conv.weight, self.conv.bias, self.conv.padding[0], None)
         i, j, f, o = torch.chunk(gates, 4, dim=1)
         new_c = c * torch.sigmoid(f + self.forget_bias) + torch.sigmoid(i) * torch.tanh(j)
         new_h = torch.tanh(new_c) * torch.sigmoid(o)

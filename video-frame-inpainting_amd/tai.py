@@ -28,6 +28,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .conv_ops import conv_bias_act
 from .mcnet import IndexedConvs, MCNet, Residual, _conv_relu_chain
 from .separable_convolution import SeparableConvolution
 from .upsample import upsample2x
@@ -62,7 +63,7 @@ class KernelGeneratorBlock(IndexedConvs):
     def forward(self, x):
         convs = self.convs()
         x = _conv_relu_chain(x, convs[:-1])
-        return convs[-1](_up2(x)).contiguous()
+        return conv_bias_act(_up2(x), convs[-1].weight, convs[-1].bias, 1, None).contiguous()
 
 
 def create_1d_kernel_generator_block(num_layers, kf_dim, ks):
@@ -76,7 +77,8 @@ class UpsampleBlock(IndexedConvs):
         super().__init__([(1, nn.Conv2d(cin, cout, 3, stride=1, padding=1))])
 
     def forward(self, x):
-        return torch.relu(self.convs()[0](_up2(x)))
+        c = self.convs()[0]
+        return conv_bias_act(_up2(x), c.weight, c.bias, 1, 'relu')
 
 
 def create_encoder_blocks(start_i, end_i, layers, if_dim, kf_dim):
