@@ -210,5 +210,54 @@ def main():
             print('tai_%s.npz: %d arrays, %d params' % (tag, len(to), sum(p.numel() for p in tm.parameters())))
 
 
+def ablations():
+    """bi-TWI, bi-TWA, bi-SA and TW_P_F runs of the reference's classes -> ablations.npz."""
+    from src.models.twi import twi
+    from src.models.bi_twa import bi_twa
+    from src.models.bi_sa import bi_sa
+    from src.models.tw_p_f import tw_p_f
+    from oracle import sepconv_oracle
+    g = torch.Generator().manual_seed(4321)
+    out = {}
+
+    def int_state(self, batch_size, image_size):
+        return torch.zeros(batch_size, 8 * self.gf_dim, image_size[0] // 8, image_size[1] // 8)
+
+    def cpu_sepconv(inp, v, h, ks=51):
+        return torch.from_numpy(sepconv_oracle.forward(inp.numpy(), v.numpy(), h.numpy(), ks))
+
+    def prep_gen(gen):
+        gen.conv_lstm_cell.conv.padding = (1, 1)
+        gen.get_initial_conv_lstm_state = types.MethodType(int_state, gen)
+
+    with torch.no_grad():
+        m = twi.TimeWeightedInterpolationFillInModel(4, 1, 3, 7, num_block=5, kf_dim=2)
+        seeded_init(m, 41); fix_upsamples(m); prep_gen(m.mcnet)
+        m.interp_net.separableConvolution = cpu_sepconv
+        P, Fo = torch.tanh(rnd(g, 2, 3, 1, 32, 32)), torch.tanh(rnd(g, 2, 2, 1, 32, 32))
+        o = m(3, P, Fo)
+        out.update({'twi/P': P.numpy(), 'twi/F': Fo.numpy()})
+        out.update({'twi/out/' + k: v.numpy() for k, v in o.items()})
+        out.update({'twi/w/' + k: v for k, v in sd_np(m).items()})
+        for tag, cls, c_dim in (('bi_twa', bi_twa.BidirectionalTimeWeightedAverageFillInModel, 1),
+                                ('bi_sa', bi_sa.BidirectionalSimpleAverageFillInModel, 3)):
+            m = cls(4, c_dim, 3)
+            seeded_init(m, 42 + c_dim); prep_gen(m.generator)
+            P, Fo = torch.tanh(rnd(g, 2, 3, c_dim, 32, 32)), torch.tanh(rnd(g, 2, 3, c_dim, 32, 32))
+            o = m(4, P, Fo)
+            out.update({tag + '/P': P.numpy(), tag + '/F': Fo.numpy()})
+            out.update({tag + '/out/' + k: v.numpy() for k, v in o.items()})
+            out.update({tag + '/w/' + k: v for k, v in sd_np(m).items()})
+        m = tw_p_f.TimeWeightedPFFillInModel()
+        P, Fo = torch.tanh(rnd(g, 2, 2, 3, 8, 8)), torch.tanh(rnd(g, 2, 2, 3, 8, 8))
+        out.update({'tw_p_f/P': P.numpy(), 'tw_p_f/F': Fo.numpy(), 'tw_p_f/out/pred': m(3, P, Fo)['pred'].numpy()})
+    np.savez_compressed(os.path.join(HERE, 'ablations.npz'), **out)
+    print('ablations.npz: %d arrays' % len(out))
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'ablations':
+        install_shims()
+        ablations()
+    else:
+        main()

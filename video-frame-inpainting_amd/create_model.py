@@ -1,13 +1,15 @@
 """``model_key`` -> model (reference src/models/create_model.py:19-111), for the keys on the bi-TAI hot path.
 
-Kept: the named keys ``TAI_gray`` / ``TAI_color`` (and the MC-Net baseline that shares every block), the fallback to
-a JSON file path and then to an inline JSON string ``{"class", "args", "kwargs"}`` (:88-111).  The other keys of the
-reference (SCT, SloMo, optical flow, TWI, bi-SA, bi-TWA, TW_P_F) are different models outside this path; asking for
-one raises with the list of supported keys instead of silently building something else.
+Kept: the named keys ``TAI_gray`` / ``TAI_color``, the models built from the same blocks (MC-Net baseline, bi-TWI, bi-TWA,
+bi-SA, TW_P_F: SURVEY.md 8f rank 1), the fallback to a JSON file path and then to an inline JSON string ``{"class",
+"args", "kwargs"}`` (:88-111).  The other keys of the reference (SCT, SloMo, optical flow) are different model families
+outside this path; asking for one raises with the list of supported keys instead of silently building something else.
 """
 import json
 import os
 
+from .ablations import (BidirectionalSimpleAverageFillInModel, BidirectionalTimeWeightedAverageFillInModel,
+                        TimeWeightedInterpolationFillInModel, TimeWeightedPFFillInModel)
 from .mcnet import MCNetFillInModel
 from .tai import TAIFillInModel
 
@@ -16,8 +18,18 @@ _BUILDERS = {
     'TAI_color': lambda: TAIFillInModel(64, 3, 3, 51, num_block=4),         # create_model.py:29-30
     'MCNet_gray': lambda: MCNetFillInModel(64, 1, 3),                       # create_model.py:33-34
     'MCNet_color': lambda: MCNetFillInModel(64, 3, 3),                      # create_model.py:35-36
+    # ablations on the same blocks (create_model.py:73-86)
+    'TimeWeightedInterpolationFillInModel_gray': lambda: TimeWeightedInterpolationFillInModel(64, 1, 3, 51, num_block=5),
+    'TimeWeightedInterpolationFillInModel_color': lambda: TimeWeightedInterpolationFillInModel(64, 3, 3, 51, num_block=4),
+    'BidirectionalSimpleAverageFillInModel_gray': lambda: BidirectionalSimpleAverageFillInModel(64, 1, 3),
+    'BidirectionalSimpleAverageFillInModel_color': lambda: BidirectionalSimpleAverageFillInModel(64, 3, 3),
+    'BidirectionalTimeWeightedAverageFillInModel_gray': lambda: BidirectionalTimeWeightedAverageFillInModel(64, 1, 3),
+    'BidirectionalTimeWeightedAverageFillInModel_color': lambda: BidirectionalTimeWeightedAverageFillInModel(64, 3, 3),
+    'TimeWeightedPFFillInModel': lambda: TimeWeightedPFFillInModel(),
 }
-_CLASSES = {'TAIFillInModel': TAIFillInModel, 'MCNetFillInModel': MCNetFillInModel}
+_CLASSES = {c.__name__: c for c in (TAIFillInModel, MCNetFillInModel, TimeWeightedInterpolationFillInModel,
+                                    BidirectionalSimpleAverageFillInModel, BidirectionalTimeWeightedAverageFillInModel,
+                                    TimeWeightedPFFillInModel)}
 
 
 def supported_model_keys():

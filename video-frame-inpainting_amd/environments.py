@@ -25,6 +25,8 @@ from .graph import GraphedForward
 from .losses import GDL
 from .mcnet import MCNetFillInModel
 from .sn_discriminator import SNDiscriminator
+from .ablations import (BidirectionalSimpleAverageFillInModel, BidirectionalTimeWeightedAverageFillInModel,
+                        TimeWeightedInterpolationFillInModel, TimeWeightedPFFillInModel)
 from .tai import TAIFillInModel
 from .util import inverse_transform, move_to_devices, weights_init
 
@@ -33,7 +35,7 @@ def create_eval_environment(fill_in_model, checkpoints_dir, name, snapshot_file_
                             load_snapshot=True, use_graph=False):
     env = BaseVideoFillInEnvironment(fill_in_model, checkpoints_dir, name, padding_size, device=device,
                                      use_graph=use_graph)
-    if load_snapshot:
+    if load_snapshot and not isinstance(fill_in_model, TimeWeightedPFFillInModel):   # environments.py:57-58
         env.load(snapshot_file_name)
     print('Loaded evaluation environment')
     return env
@@ -41,8 +43,10 @@ def create_eval_environment(fill_in_model, checkpoints_dir, name, snapshot_file_
 
 def create_training_environment(fill_in_model, c_dim, checkpoints_dir, name, max_K, max_T, max_F, image_size, alpha,
                                 beta, lr, beta1, df_dim, Ip, disc_window_size, padding_size, device=None):
-    if isinstance(fill_in_model, TAIFillInModel):
-        env = TAITrainingEnvironment(fill_in_model, checkpoints_dir, name, image_size, c_dim, alpha, beta, lr, beta1,
+    if isinstance(fill_in_model, (TAIFillInModel, TimeWeightedInterpolationFillInModel,
+                                  BidirectionalSimpleAverageFillInModel, BidirectionalTimeWeightedAverageFillInModel)):
+        env = TAITrainingEnvironment(      # environments.py:29-31
+            fill_in_model, checkpoints_dir, name, image_size, c_dim, alpha, beta, lr, beta1,
                                      df_dim, Ip, disc_window_size, max_K, max_T, max_F, padding_size, device=device)
     elif isinstance(fill_in_model, MCNetFillInModel):
         env = MCNetTrainingEnvironment(fill_in_model, checkpoints_dir, name, image_size, c_dim, alpha, beta, lr, beta1,

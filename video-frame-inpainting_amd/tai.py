@@ -105,12 +105,12 @@ def create_decoder_blocks(num_block, kf_dim, layers, rc_loc):
 class TAI(nn.Module):
     """Time-aware interpolation ("kernel") network, tai.py:123-237."""
 
-    def __init__(self, gf_dim, ks, num_block, layers, kf_dim):
+    def __init__(self, gf_dim, ks, num_block, layers, kf_dim, rc_loc=4):
         super().__init__()
         assert layers >= 1, 'layers in per block should be no smaller than 1, but layers=[%d]' % layers
         assert num_block >= 4, '# blocks should be no less than 3, but num_block=%d' % num_block
         self.kf_dim, self.ks, self.layers, self.num_block = kf_dim, ks, layers, num_block
-        self.rc_loc = 4
+        self.rc_loc = rc_loc      # 4 for TAI (tai.py:152); -1 = never inject the time ratio (TWI, twi.py:162)
         self.moduleConv = nn.ModuleList(create_encoder_blocks(3, num_block, layers, gf_dim * 8 * 2, kf_dim))
         deconv, upsample = create_decoder_blocks(num_block - 1, kf_dim, layers, self.rc_loc)
         self.moduleDeconv = nn.ModuleList(deconv)
@@ -146,6 +146,36 @@ class TAI(nn.Module):
         return dot1, dot2
 
 
+def bidirectional_inputs(preceding_frames, following_frames):
+    """Content frames and gray difference frames of both temporal directions (tai.py:63-74; the same block opens
+    twi.py, bi_sa.py and bi_twa.py): -> (diff_in, xt, diff_in_F, xt_F)."""
+    xt = preceding_frames[:, -1]
+    xt_F = following_frames[:, 0]
+    gray_p = gray01(preceding_frames)
+    diff_in = gray_p[:, 1:] - gray_p[:, :-1]
+    gray_f = torch.flip(gray01(following_frames), dims=[1])
+    diff_in_F = gray_f[:, 1:] - gray_f[:, :-1]
+    return diff_in, xt, diff_in_F, xt_F
+
+
+def generate_both_directions(generator, K, Fn, T, diff_in, xt, diff_in_F, xt_F, fuse=True):
+    """The two shared-weight MC-Net passes (forward in time, backward in time), batched into one when K == F;
+    the backward lists are returned already reversed into forward time order (tai.py:77-83)."""
+    if fuse and K == Fn:
+        B = xt.shape[0]
+        pred, dyn, cont, res = generator(K, T, torch.cat([diff_in, diff_in_F], 0), torch.cat([xt, xt_F], 0))
+        fwd = ([p[:B] for p in pred], [d[:B] for d in dyn], [c[:B] for c in cont], [[r[:B] for r in rs] for rs in res])
+        bwd = ([p[B:] for p in pred], [d[B:] for d in dyn], [c[B:] for c in cont], [[r[B:] for r in rs] for rs in res])
+    else:
+        fwd, bwd = generator(K, T, diff_in, xt), generator(Fn, T, diff_in_F, xt_F)
+    return fwd, tuple(x[::-1] for x in bwd)
+
+
+def middle_frame_weights(T):
+    """w[t] = (t+1)/(T+1): weight of the FOLLOWING side at middle frame t (tai.py:90)."""
+    return np.linspace(0, 1, num=T + 2).tolist()[1:-1]
+
+
 class TAIFillInModel(nn.Module):
     """tai.py:14-120."""
 
@@ -160,31 +190,14 @@ class TAIFillInModel(nn.Module):
         self.kernelnet = TAI(gf_dim, ks, num_block, layers, kf_dim)
         self.fuse_directions = True
 
-    def _generate_both(self, K, Fn, T, diff_in, xt, diff_in_F, xt_F):
-        """The two shared-weight MC-Net passes; batched into one when they have the same length."""
-        if self.fuse_directions and K == Fn:
-            B = xt.shape[0]
-            pred, dyn, cont, res = self.generator(K, T, torch.cat([diff_in, diff_in_F], 0), torch.cat([xt, xt_F], 0))
-            fwd = ([p[:B] for p in pred], [d[:B] for d in dyn], [c[:B] for c in cont], [[r[:B] for r in rs] for rs in res])
-            bwd = ([p[B:] for p in pred], [d[B:] for d in dyn], [c[B:] for c in cont], [[r[B:] for r in rs] for rs in res])
-            return fwd, bwd
-        return self.generator(K, T, diff_in, xt), self.generator(Fn, T, diff_in_F, xt_F)
-
     def forward(self, T, preceding_frames, following_frames):
         K = preceding_frames.size(1)
         Fn = following_frames.size(1)
-        xt = preceding_frames[:, -1]
-        xt_F = following_frames[:, 0]
-        gray_p = gray01(preceding_frames)
-        diff_in = gray_p[:, 1:] - gray_p[:, :-1]
-        gray_f = torch.flip(gray01(following_frames), dims=[1])
-        diff_in_F = gray_f[:, 1:] - gray_f[:, :-1]
+        diff_in, xt, diff_in_F, xt_F = bidirectional_inputs(preceding_frames, following_frames)
+        (f_pred, f_dyn, f_cont, f_res), (b_pred, b_dyn, b_cont, b_res) = generate_both_directions(
+            self.generator, K, Fn, T, diff_in, xt, diff_in_F, xt_F, fuse=self.fuse_directions)
 
-        (f_pred, f_dyn, f_cont, f_res), (b_pred, b_dyn, b_cont, b_res) = \
-            self._generate_both(K, Fn, T, diff_in, xt, diff_in_F, xt_F)
-        b_pred, b_dyn, b_cont, b_res = b_pred[::-1], b_dyn[::-1], b_cont[::-1], b_res[::-1]
-
-        w = np.linspace(0, 1, num=T + 2).tolist()[1:-1]
+        w = middle_frame_weights(T)
         combination, out1, out2 = [], [], []
         for t in range(T):
             merged = {1: self.merge_residual2(f_res[t][1], b_res[t][1]),
