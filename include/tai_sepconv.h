@@ -78,6 +78,11 @@ int tai_bias_act_inplace(float* x, const float* bias, int N, int C, int HW, int 
  * Returns the previous value. */
 int tai_sepconv_set_forward_variant(int variant);
 
+/* grad_input kernel of tai_sepconv_backward: 0 = automatic (LDS row-scatter when ks == 51, W % 4 == 0, C in {1, 3};
+ * accumulates with float atomics: last bits depend on arrival order), 1 = bounds-checked gather (any shape, bit-
+ * reproducible, ~40x slower).  Returns the previous value. */
+int tai_sepconv_set_grad_input_variant(int variant);
+
 /* Algorithmic HBM bytes of one call: each operand read once, each result written once. */
 long long tai_sepconv_forward_bytes(int B, int C, int H, int W, int ks);
 long long tai_sepconv_backward_bytes(int B, int C, int H, int W, int ks);

@@ -130,6 +130,25 @@ def test_adjoint_identity_at_full_size():
             assert abs(lhs - rhs) <= 1e-4 * (1 + abs(lhs)), (lhs, rhs)
 
 
+def test_both_grad_input_kernels_match_oracle():
+    # LDS row-scatter (default when tileable) and the reference-style gather must agree with the oracle and each other
+    inp, v, h, gO = _case(2, 3, 20, 132, 51, 12)
+    _, _, _ = None, None, None
+    rI, _, _ = so.backward(gO.numpy(), inp.numpy(), v.numpy(), h.numpy(), 51, f64=True)
+    L = _native.lib()
+    got = []
+    for variant in (0, 1):
+        prev = L.tai_sepconv_set_grad_input_variant(variant)
+        try:
+            di = inp.to(DEV).requires_grad_()
+            vfi.SeparableConvolution.apply(di, v.to(DEV), h.to(DEV), 51).backward(gO.to(DEV))
+            got.append(di.grad.cpu().numpy())
+        finally:
+            L.tai_sepconv_set_grad_input_variant(prev)
+        assert _rel(got[-1], rI) < BWD_TOL
+    assert _rel(got[0], got[1].astype(np.float64)) < BWD_TOL
+
+
 def test_partial_gradients_and_error_reporting():
     inp, v, h, gO = _case(1, 1, 8, 128, 51, 4)
     di, dv, dh = inp.to(DEV), v.to(DEV).requires_grad_(), h.to(DEV)       # only gV requested

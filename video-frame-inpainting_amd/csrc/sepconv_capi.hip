@@ -21,6 +21,7 @@ namespace {
 
 thread_local char g_err[256] = "";
 int g_fwd_variant = 0;
+int g_gi_variant = 0;   // 0 automatic (LDS row-scatter when tileable), 1 force the gather kernel
 
 int fail(int code, const char* fmt, const char* what) {
     std::snprintf(g_err, sizeof(g_err), fmt, what);
@@ -177,6 +178,12 @@ int tai_sepconv_set_forward_variant(int variant) {
     return prev;
 }
 
+int tai_sepconv_set_grad_input_variant(int variant) {
+    const int prev = g_gi_variant;
+    g_gi_variant = variant;
+    return prev;
+}
+
 long long tai_sepconv_forward_bytes(int B, int C, int H, int W, int ks) {
     const long long Hp = H + ks - 1, Wp = W + ks - 1;
     return 4LL * ((long long)B * C * Hp * Wp + 2LL * B * ks * H * W + (long long)B * C * H * W);
@@ -304,6 +311,25 @@ int tai_sepconv_backward(const float* grad_output, const float* input, const flo
         }
     }
     if (grad_input) {
+        if (tileable && g_gi_variant != 1) {
+            // LDS row-scatter (C == 1 or 3 here): the kernel accumulates into gI with atomics, so zero it first
+            const size_t bytes = (size_t)B * C * (H + ks - 1) * (W + ks - 1) * sizeof(float);
+            if (hipMemsetAsync(grad_input, 0, bytes, s) != hipSuccess) return fail(TAI_SEPCONV_ELAUNCH, "%s", "hipMemsetAsync(gI)");
+            const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W, tiles_y = (H + 7) / 8;
+            const dim3 grid(B * tiles_x * tiles_y), block(512);
+            const size_t lds = ((size_t)C * 58 * 180 + 8 * 2 * 320) * sizeof(float);
+            if (C == 1) {
+                auto kern = bwd::sepconv_grad_i_rows<51, 1>;
+                if (int rc = allow_lds(kern, lds)) return rc;
+                hipLaunchKernelGGL(kern, grid, block, lds, s, grad_output, vertical, horizontal, grad_input, H, W, tiles_x, tiles_y);
+            } else {
+                auto kern = bwd::sepconv_grad_i_rows<51, 3>;
+                if (int rc = allow_lds(kern, lds)) return rc;
+                hipLaunchKernelGGL(kern, grid, block, lds, s, grad_output, vertical, horizontal, grad_input, H, W, tiles_x, tiles_y);
+            }
+            if (int rc = check_launch("sepconv_grad_i_rows")) return rc;
+            return TAI_SEPCONV_OK;
+        }
         const int n = B * (H + ks - 1) * (W + ks - 1);
         const dim3 grid((n + 255) / 256), block(256);
         int c0 = 0;
