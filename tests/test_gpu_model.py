@@ -154,3 +154,54 @@ def test_ablation_models_on_gpu_match_reference_runs(golden_dir):
             o = model(T, P, Fo)
         for k in outs:
             np.testing.assert_allclose(o[k].cpu().numpy(), outs[k], rtol=0, atol=2e-4, err_msg=tag + ' ' + k)
+
+
+def _tiny(c_dim, num_block, seed):
+    torch.manual_seed(seed)
+    m = vfi.TAIFillInModel(8, c_dim, 3, 51, num_block=num_block, kf_dim=4)
+    m.apply(vfi.util.weights_init)
+    return m, {k: v.clone() for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize('name,c_dim,num_block,H,W,K,T,F', [
+    ('cfg4-shape: colour 256x256, K=F=3, T=5', 3, 4, 256, 256, 3, 5, 3),
+    ('cfg5-shape: long gap T=10', 1, 5, 128, 128, 5, 10, 5),
+    ('minimum context K=F=2, T=1, non-square', 1, 5, 64, 96, 2, 1, 2),
+    ('K != F: the two directions cannot be fused', 3, 4, 32, 48, 4, 3, 2),
+])
+def test_other_baseline_config_shapes_match_cpu_oracle(name, c_dim, num_block, H, W, K, T, F):
+    m, sd = _tiny(c_dim, num_block, 11)
+    clips = synthetic.make_clips(1, K + T + F, c_dim, H, W, 77)
+    P, GT, Fo = (torch.from_numpy(x) for x in synthetic.split_clip(clips, K, T, F))
+    with torch.no_grad():
+        ref = tai_oracle.tai_forward(sd, c_dim, num_block, 51, T, P, Fo)
+        out = m.to(DEV).eval()(T, P.to(DEV), Fo.to(DEV))
+    for k in KEYS:
+        assert out[k].shape == ref[k].shape == (1, T, c_dim, H, W)
+        assert float((out[k].cpu() - ref[k]).abs().max()) <= 2e-4, (name, k)
+    p_gpu, s_gpu, _ = metrics.compute_errors(out['pred'].cpu().numpy(), GT.numpy())
+    p_cpu, s_cpu, _ = metrics.compute_errors(ref['pred'].numpy(), GT.numpy())
+    assert np.max(np.abs(p_gpu - p_cpu)) <= 0.01 and np.max(np.abs(s_gpu - s_cpu)) <= 1e-4
+
+
+def test_predict_and_train_drivers_run_end_to_end(tmp_path, monkeypatch):
+    import predict
+    import train
+    monkeypatch.chdir(tmp_path)
+    spec = '{"class": "TAIFillInModel", "args": [4, 1, 3, 51], "kwargs": {"num_block": 5, "kf_dim": 2}}'
+    common = ['--name', 'drv', '--K', '3', '--T', '2', '--F', '3', '--c_dim', '1', '--image_size', '32', '--model_key', spec,
+              '--checkpoints_dir', str(tmp_path / 'ckpt')]
+    train.main(common + ['--batch_size', '2', '--max_iter', '2', '--synthetic', '4', '--print_freq', '1', '--df_dim', '8'])
+    assert (tmp_path / 'ckpt' / 'drv' / 'model_latest.ckpt').exists()
+    # predict.py loads what train.py saved (snapshot['generator']) and writes the reference's PNG set
+    predict.main(common + ['--batch_size', '2', '--synthetic', '3', '--qual_result_root', str(tmp_path / 'res'),
+                           '--snapshot_file_name', 'model_latest.ckpt', '--intermediate_preds'])
+    files = sorted(os.listdir(tmp_path / 'res' / 'synthetic_000000'))
+    want = (['gt_preceding_%04d.png' % i for i in range(3)] + ['gt_middle_%04d.png' % i for i in (3, 4)] +
+            ['gt_following_%04d.png' % i for i in (5, 6, 7)] +
+            ['%s_%04d.png' % (p, i) for p in ('pred_middle', 'pred_middle_forward', 'pred_middle_backward',
+                                                'interp_net_outputs_1', 'interp_net_outputs_2') for i in (3, 4)])
+    assert files == sorted(want)
+    from PIL import Image
+    im = np.asarray(Image.open(tmp_path / 'res' / 'synthetic_000002' / 'pred_middle_0003.png'))
+    assert im.shape == (32, 32) and im.dtype == np.uint8
