@@ -307,3 +307,30 @@ def test_ablation_models_match_reference_runs(golden_dir):
     np.testing.assert_allclose(ab.TimeWeightedPFFillInModel()(3, P, Fo)['pred'].numpy(), z['tw_p_f/out/pred'], rtol=1e-6, atol=1e-7)
     assert isinstance(vfi.create_model('TimeWeightedInterpolationFillInModel_gray'), ab.TimeWeightedInterpolationFillInModel)
     assert isinstance(vfi.create_model('BidirectionalSimpleAverageFillInModel_color'), ab.BidirectionalSimpleAverageFillInModel)
+
+
+def test_quant_eval_pipeline_on_png_frames(tmp_path):
+    # predict.py's PNG layout -> compute_quant_results.py -> results.npz -> summarize_quant_results.py table
+    import compute_quant_results, summarize_quant_results
+    from PIL import Image
+    rs = np.random.RandomState(3)
+    K, T = 2, 3
+    want_p = np.zeros((2, T))
+    for n in range(2):
+        d = tmp_path / 'qual' / ('video_%d' % n)
+        os.makedirs(d)
+        for t in range(K, K + T):
+            gt = rs.randint(0, 256, (24, 20)).astype(np.uint8)
+            pred = np.clip(gt.astype(int) + rs.randint(-6, 7, gt.shape), 0, 255).astype(np.uint8)
+            Image.fromarray(gt).save(d / ('gt_middle_%04d.png' % t))
+            Image.fromarray(pred).save(d / ('pred_middle_%04d.png' % t))
+            want_p[n, t - K] = metrics.psnr_uint8(pred, gt)
+    compute_quant_results.main([str(tmp_path / 'qual'), str(tmp_path / 'quant'), str(K), str(T)])
+    z = np.load(tmp_path / 'quant' / 'results.npz')
+    assert z['psnr'].shape == (2, T) and z['ssim'].shape == (2, T) and len(z['video']) == 2
+    np.testing.assert_allclose(z['psnr'], want_p)
+    summarize_quant_results.main([str(tmp_path / 'tables'), '--results', '%s:bi-TAI (ours)' % (tmp_path / 'quant')])
+    txt = open(tmp_path / 'tables' / 'psnr_perf_summary.txt').read()
+    assert 'bi-TAI (ours)' in txt and ('%.2f' % want_p.mean(axis=1).mean()) in txt and txt.startswith('+')
+    with pytest.raises(RuntimeError):
+        compute_quant_results.main([str(tmp_path / 'qual'), str(tmp_path / 'quant'), '5', '5'])
