@@ -95,7 +95,12 @@ class BaseVideoFillInEnvironment(object):
         save_path = os.path.join(self.save_dir, snapshot_file_name)
         if os.path.isfile(save_path):
             print('=> loading snapshot from {}'.format(save_path))
-            snapshot = torch.load(save_path, map_location=self.device, weights_only=False)
+            try:
+                snapshot = torch.load(save_path, map_location=self.device, weights_only=False)
+            except UnicodeDecodeError:
+                # the published checkpoints were pickled by Python 2.7 / torch 0.3.1 (bashes/download/
+                # download_model_checkpoints.bash): their byte strings need latin1
+                snapshot = torch.load(save_path, map_location=self.device, weights_only=False, encoding='latin1')
         else:
             raise RuntimeError('Failed to find snapshot at path %s' % save_path)
         self.generator.load_state_dict(snapshot['generator'])
