@@ -87,7 +87,8 @@ def sepconv_roofline(device, B, iters=200, warmup=20, settle_s=2.0):
     pmc = os.path.join(ROOT, 'profiles', 'sepconv_fwd_pmc.json')
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            rec = json.load(open(pmc))
+            traffic = rec.get('hbm_bytes_per_launch') if rec.get('shape') == [B, C_, H_, W_] else None
         except Exception:
             traffic = None
     return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -211,7 +212,8 @@ def main():
     dt = time.perf_counter() - t0
     log('timed %d steps: %.3f s' % (args.steps, dt))
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        on_gloo = torch.distributed.get_backend() == 'gloo'
+        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if on_gloo else device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -223,8 +225,8 @@ def main():
         'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'configs[1]: bi-TAI (TAI_gray) 128x128 grayscale K=F=5 T=5 inference, batch 32 per GPU, '
-                               'sepconv HIP kernels + %s' % ('eager launches' if args.no_graph else 'hipGraph replay'),
+        'config': {'workload': 'configs[1]: bi-TAI (TAI_gray) 128x128 grayscale K=F=5 T=5 inference, batch %d per GPU, '
+                               'sepconv HIP kernels + %s' % (B, 'eager launches' if args.no_graph else 'hipGraph replay'),
                    'clips_per_gpu': B, 'global_clips': world * B, 'parallelism': 'clip-sharded x%d, no collective' % world,
                    'weights': 'seeded xavier-normal init (torch.manual_seed(0))'},
     }

@@ -24,6 +24,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('TAI_REHEARSE_ON_ONE_GPU') == '1':
+        # rehearsal of the N-rank code path on a one-GPU box: every rank drives cuda:0 and the (tiny) control-plane
+        # collectives go over gloo.  Never used for measurements.
+        backend, local_rank = 'gloo', 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
