@@ -44,9 +44,17 @@ bool dims_ok(int B, int C, int H, int W, int ks) {
     return (long long)B * C * Hp * Wp < lim && (long long)B * ks * H * W < lim;
 }
 
+// Raises the kernel's dynamic-LDS limit past the default 64 KiB.  Done once per kernel and size (the attribute sticks),
+// so the steady-state launch path makes no runtime call besides the launch itself.
 template <typename KernelT>
 int allow_lds(KernelT kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return TAI_SEPCONV_OK;
+    static thread_local const void* done_kernel[32];
+    static thread_local size_t done_bytes[32];
+    static thread_local int n_done = 0;
+    for (int i = 0; i < n_done; ++i)
+        if (done_kernel[i] == reinterpret_cast<const void*>(kernel) && done_bytes[i] >= bytes) return TAI_SEPCONV_OK;
+    if (n_done < 32) { done_kernel[n_done] = reinterpret_cast<const void*>(kernel); done_bytes[n_done] = bytes; ++n_done; }
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) {
