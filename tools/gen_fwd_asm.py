@@ -43,7 +43,8 @@ ACC = lambda p: 204 + 2 * p
 O = lambda p: 212 + 2 * p
 BUF = lambda k: 220 + 4 * (k % NBUF)   # k = running chunk number (14 per row: the rotation shifts per row)
 VV = 244              # v values of the row: v[244:247]
-V_ROW, V_RING, V_GOFF, V_TMP = 240, 241, 242, 243
+V_ROW_IN, V_RING, V_GOFF, V_TMP = 240, 241, 242, 243
+V_ROW = 248          # running copy of the row window address (v240 itself is left untouched)
 
 # scalar registers (all named explicitly and listed as clobbers, except the inputs)
 S_VPTR_IN = 's[60:61]'   # input: &v[b, 0, 0, 0]
@@ -160,6 +161,7 @@ def gen():
     for p in range(4):
         L.append('v_mov_b32 v%d, 0' % O(p))
         L.append('v_mov_b32 v%d, 0' % (O(p) + 1))
+    L.append('v_mov_b32 v%d, v%d' % (V_ROW, V_ROW_IN))
     L.append('s_mov_b32 %s, s60' % S_PTR_LO)
     L.append('s_mov_b32 %s, s61' % S_PTR_HI)
     for r in range(RING):
@@ -265,6 +267,7 @@ def gen_b():
     L = []
     for r in range(0, 204, 2):
         L.append('v_mov_b64 v[%d:%d], 0' % (r, r + 1))
+    L.append('v_mov_b32 v%d, v%d' % (V_ROW, V_ROW_IN))
     L.append('s_mov_b32 %s, s60' % S_PTR_LO)
     L.append('s_mov_b32 %s, s61' % S_PTR_HI)
     for r in range(RING):
@@ -325,10 +328,10 @@ def main():
         for l in lines:
             f.write('    "%s\\n" \\\n' % l)
         f.write('    ""\n')
-        clob_b = ['v%d' % r for r in list(range(220, 240)) + [243, 244, 245, 246, 247]]
+        clob_b = ['v%d' % r for r in list(range(220, 240)) + [243, 244, 245, 246, 247, 248]]
         clob_b += ['s%d' % r for r in range(64, 71)] + ['scc', 'memory']
         f.write('#define TAI_FWD_ROWLOOP_B_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob_b))
-        clob = ['v%d' % r for r in list(range(204, 212)) + list(range(220, 240)) + [243, 244, 245, 246, 247]]
+        clob = ['v%d' % r for r in list(range(204, 212)) + list(range(220, 240)) + [243, 244, 245, 246, 247, 248]]
         clob += ['s%d' % r for r in range(64, 71)] + ['scc', 'memory']   # m0 is written too; hipcc reloads it before each of its own uses
         f.write('#define TAI_FWD_ROWLOOP_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob))
     print('wrote %s' % out)

@@ -127,6 +127,19 @@ int fwd_ab_all_channels(const float* in, const float* v, const float* h, float* 
     return TAI_SEPCONV_OK;
 }
 
+template <int WAVES>
+int fwd_asm_channel_loop(const float* in, const float* v, const float* h, float* out, int B, int C, int H, int W,
+                          hipStream_t s) {
+    const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W;
+    const int tiles_y = (H + 2 * WAVES - 1) / (2 * WAVES);
+    const size_t patch = (size_t)(2 * WAVES + 50) * 180 * sizeof(float);
+    const size_t lds = ((patch + 1023) & ~(size_t)1023) + (size_t)WAVES * TAI_FWD_ROWLOOP_RING_SLOTS * 1024;
+    auto kern = fwd::sepconv_forward_asm_channels<WAVES>;
+    if (int rc = allow_lds(kern, lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(WAVES * 64), lds, s, in, v, h, out, C, H, W, tiles_x, tiles_y);
+    return check_launch("sepconv_forward_asm_channels");
+}
+
 template <int KS>
 int fwd_packed_all_channels(const float* in, const float* v, const float* h, float* out, int B, int C,
                             int H, int W, hipStream_t s) {
@@ -211,8 +224,8 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
 
     int variant = g_fwd_variant;
     const bool tileable = (ks == 51) && (W % 4 == 0);
-    // default: mixed type-A / type-B hand-scheduled kernel for single-channel frames, half-wave tap split for RGB
-    if (variant == 0) variant = !tileable ? 1 : (C == 1 ? 13 : 3);
+    // default: mixed type-A / type-B hand-scheduled kernel for single-channel frames; taps-once channel loop otherwise
+    if (variant == 0) variant = !tileable ? 1 : (C == 1 ? 13 : 15);
     if (variant != 1 && !tileable)
         return fail(TAI_SEPCONV_EINVAL, "%s", "tiled forward variants need ks == 51 and W % 4 == 0");
     switch (variant) {
@@ -237,6 +250,8 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 108: return fwd_ab_all_channels<3, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 106: return fwd_ab_all_channels<0, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 107: return fwd_ab_all_channels<2, 3>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 14: return fwd_asm_channel_loop<8>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 15: return fwd_asm_channel_loop<4>(input, vertical, horizontal, output, B, C, H, W, s);
         case 111: return fwd_asm_all_channels<false, 0, 8, 2>(input, vertical, horizontal, output, B, C, H, W, s);
         case 112: return fwd_asm_all_channels<false, 0, 8, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 103: return fwd_asm_all_channels<false, 3, 8>(input, vertical, horizontal, output, B, C, H, W, s);
