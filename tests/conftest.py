@@ -17,3 +17,14 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _native_library_built():
+    """The C-ABI library is a build artefact (git-ignored): compile it for gfx950 if it is missing or stale.  hipcc
+    cross-compiles without a GPU, so this also holds for the CPU-only test run."""
+    import shutil
+    from video_frame_inpainting_amd import _native
+    if shutil.which('hipcc'):
+        _native.build()
+    yield
