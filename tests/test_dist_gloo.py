@@ -59,3 +59,39 @@ def test_two_rank_data_parallel_step(tmp_path):
     a = torch.load(tmp_path / 'rank0.pt')
     b = torch.load(tmp_path / 'rank1.pt')
     assert torch.equal(a, b)            # identical replicas after broadcast + averaged-gradient step
+
+
+def _env_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend='gloo')
+    import video_frame_inpainting_amd as vfi
+    from video_frame_inpainting_amd import synthetic
+    from video_frame_inpainting_amd.environments import create_training_environment
+    torch.manual_seed(7 + rank)                       # different initial weights per rank: sync_replicas must fix that
+    np.random.seed(0)                                 # identical (K, T, F) draws
+    model = vfi.MCNetFillInModel(4, 1, 3)             # the training environment's G/D step without the GPU-only sepconv
+    env = create_training_environment(model, 1, out_dir, 'dp%d' % rank, 3, 2, 3, [32, 32], 1.0, 0.02, 1e-3, 0.5, 4, 2, 3,
+                                      [0, 0], device='cpu')
+    env.sync_replicas()
+    clips = torch.from_numpy(synthetic.make_clips(2, 8, 1, 32, 32, 100 + rank))     # each rank trains on its OWN clips
+    for _ in range(2):
+        K, T, F = env.sample_KTF(True)
+        env.set_train_inputs(clips[:, :K], clips[:, K + T:K + T + F], clips[:, K:K + T])
+        env.K, env.T, env.F = K, T, F
+        env.train()
+        env.forward_train()
+        env.optimize_parameters()
+    flat = torch.cat([p.detach().reshape(-1) for p in list(env.generator.parameters()) + list(env.discriminator.parameters())])
+    torch.save((flat, (K, T, F)), os.path.join(out_dir, 'env_rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_environment_keeps_replicas_identical(tmp_path):
+    """Two ranks, different data and different initial weights: after sync_replicas and two G+D steps with the
+    gradient all-reduces of parallel.py, generator and discriminator weights are bit-identical on both ranks."""
+    mp.spawn(_env_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, ktf_a = torch.load(tmp_path / 'env_rank0.pt')
+    b, ktf_b = torch.load(tmp_path / 'env_rank1.pt')
+    assert ktf_a == ktf_b
+    assert torch.equal(a, b)
