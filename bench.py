@@ -46,7 +46,7 @@ def log(msg):
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def sepconv_roofline(device, B, iters=200, warmup=20, settle_s=2.0):
+def sepconv_roofline(device, B, iters=200, warmup=20):
     ks = 51
     g = torch.Generator().manual_seed(7)
     inp = (torch.rand(B, C_, H_ + ks - 1, W_ + ks - 1, generator=g) * 2 - 1).to(device)
@@ -76,11 +76,15 @@ def sepconv_roofline(device, B, iters=200, warmup=20, settle_s=2.0):
             e1.record()
             e1.synchronize()
             return e0.elapsed_time(e1) * 1e3 / (replays * per_graph)
-        us_hot = timed()                 # straight after the model steps: the chip is at its loaded clock
-        time.sleep(settle_s)             # ... and after a pause, at the clock an isolated kernel launch sees
-        us_settled = min(timed(), timed())
+        # Three passes of `replays` graph replays each, back to back.  The first pass right after the model steps is
+        # 5 % slower (48.4 vs 45.9 us measured): the tap planes are not yet resident in the 256 MiB Infinity Cache and
+        # the kernel's code is cold; an idle pause does NOT help (46.9 us after 2 s: the clock ramps down), so the
+        # difference is warm-up, not heat.  Reported: the mean of passes 2 and 3 (steady state), and pass 1 beside it.
+        us_first = timed()
+        us_steady = 0.5 * (timed() + timed())
+        log('sepconv forward per launch: %.2f us first pass after the model steps, %.2f us steady state' % (us_first, us_steady))
     iters = replays * per_graph
-    us = us_settled
+    us = us_steady
     nbytes = sc.forward_bytes(B, C_, H_, W_, ks)
     achieved = nbytes / us / 1e3          # GB/s
     traffic = None
@@ -93,7 +97,7 @@ def sepconv_roofline(device, B, iters=200, warmup=20, settle_s=2.0):
             traffic = None
     return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'kernel': 'sepconv_forward',
-            'shape': [B, C_, H_, W_], 'us_per_launch': round(us, 2), 'us_per_launch_right_after_model_steps': round(us_hot, 2),
+            'shape': [B, C_, H_, W_], 'us_per_launch': round(us, 2), 'us_per_launch_first_pass': round(us_first, 2),
             'algorithmic_bytes': nbytes}
 
 
