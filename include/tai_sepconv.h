@@ -85,6 +85,10 @@ int tai_sepconv_set_forward_variant(int variant);
  * reproducible, ~40x slower).  Returns the previous value. */
 int tai_sepconv_set_grad_input_variant(int variant);
 
+/* grad_vertical / grad_horizontal kernels: 0 = automatic (one fused launch of the hand-scheduled wave types when C == 1
+ * and both are requested), 1 = the two separate HIP kernels.  Returns the previous value. */
+int tai_sepconv_set_grad_taps_variant(int variant);
+
 /* Algorithmic HBM bytes of one call: each operand read once, each result written once. */
 long long tai_sepconv_forward_bytes(int B, int C, int H, int W, int ks);
 long long tai_sepconv_backward_bytes(int B, int C, int H, int W, int ks);

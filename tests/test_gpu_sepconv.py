@@ -149,6 +149,20 @@ def test_both_grad_input_kernels_match_oracle():
     assert _rel(got[0], got[1].astype(np.float64)) < BWD_TOL
 
 
+def test_fused_and_separate_tap_gradient_kernels_agree():
+    inp, v, h, gO = _case(2, 1, 24, 128, 51, 13)
+    _, rV, rH = so.backward(gO.numpy(), inp.numpy(), v.numpy(), h.numpy(), 51, f64=True)
+    L = _native.lib()
+    for variant in (0, 1):
+        prev = L.tai_sepconv_set_grad_taps_variant(variant)
+        try:
+            dv, dh = v.to(DEV).requires_grad_(), h.to(DEV).requires_grad_()
+            vfi.SeparableConvolution.apply(inp.to(DEV), dv, dh, 51).backward(gO.to(DEV))
+        finally:
+            L.tai_sepconv_set_grad_taps_variant(prev)
+        assert _rel(dv.grad.cpu().numpy(), rV) < BWD_TOL and _rel(dh.grad.cpu().numpy(), rH) < BWD_TOL
+
+
 def test_partial_gradients_and_error_reporting():
     inp, v, h, gO = _case(1, 1, 8, 128, 51, 4)
     di, dv, dh = inp.to(DEV), v.to(DEV).requires_grad_(), h.to(DEV)       # only gV requested

@@ -298,6 +298,55 @@ def gen_b():
     return L
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# gV row loop: the forward's type-A inner product without the v stream:  gV[fy] = gO * sum_fx h[fx] * in[y+fy, x+fx]
+# (single channel).  Per row: 100 v_pk_fma_f32 + 4 v_fmac_f32 + 4 v_add_f32 + 4 v_mul_f32 and ONE 16-byte store per lane
+# (s[64:65] = &gV[b, fy, 0, 0] advances by one plane per row; v242 = the lane's byte offset in the plane; lanes whose
+# pixels lie outside the image are masked out of the store with s[72:73]).  gO sits in v[244:247].
+def emit_row_gv(L, phase):
+    base = NCHUNK * phase
+    first_done = set()
+    for k in range(NCHUNK):
+        nk = k + LOOKAHEAD
+        if nk < NCHUNK:
+            emit_chunk_read(L, nk, 0, base)
+        else:
+            emit_chunk_read(L, nk - NCHUNK, PITCH_BYTES, base + NCHUNK)
+        L.append('s_waitcnt lgkmcnt(%d)' % LOOKAHEAD)
+        emit_chunk_fmas(L, k, first_done, base)
+    for p in range(4):
+        L.append('v_add_f32 v%d, v%d, v%d' % (236 + p, ACC(p), ACC(p) + 1))
+    for p in range(4):
+        L.append('v_mul_f32 v%d, v%d, v%d' % (236 + p, 244 + p, 236 + p))
+    L.append('s_and_b64 exec, exec, s[72:73]')
+    L.append('global_store_dwordx4 v%d, v[236:239], s[64:65]' % V_GOFF)
+    L.append('s_mov_b64 exec, s[74:75]')
+    L.append('s_add_u32 %s, %s, %s' % (S_PTR_LO, S_PTR_LO, S_PLANE))
+    L.append('s_addc_u32 %s, %s, 0' % (S_PTR_HI, S_PTR_HI))
+    L.append('v_add_u32 v%d, %d, v%d' % (V_ROW, PITCH_BYTES, V_ROW))
+    L.append('s_add_u32 %s, %s, 1' % (S_ROW, S_ROW))
+
+
+def gen_gv():
+    L = []
+    L.append('v_mov_b32 v%d, v%d' % (V_ROW, V_ROW_IN))
+    L.append('s_mov_b32 %s, s60' % S_PTR_LO)
+    L.append('s_mov_b32 %s, s61' % S_PTR_HI)
+    L.append('s_mov_b64 s[74:75], exec')
+    L.append('s_mov_b32 %s, 0' % S_ROW)
+    for k in range(LOOKAHEAD):
+        emit_chunk_read(L, k, 0)
+    L.append('.p2align 6')
+    L.append('1:')
+    emit_row_gv(L, 0)
+    emit_row_gv(L, 1)
+    L.append('s_cmp_lt_u32 %s, %d' % (S_ROW, KS - 1))
+    L.append('s_cbranch_scc1 1b')
+    emit_row_gv(L, 0)
+    L.append('s_waitcnt vmcnt(0) lgkmcnt(0)')
+    return L
+
+
 def main():
     global LOOKAHEAD, NBUF, ABLATE_VMCNT, ABLATE_LGKM, PRIO_ALTERNATE
     here = os.path.dirname(os.path.abspath(__file__))
@@ -328,6 +377,15 @@ def main():
         for l in lines:
             f.write('    "%s\\n" \\\n' % l)
         f.write('    ""\n')
+        lines = gen_gv()
+        f.write('// TAI_GV_ROWLOOP_ASM (gV = gO * row sums, one store per row): %d instructions.\n' % len(lines))
+        f.write('#define TAI_GV_ROWLOOP_ASM \\\n')
+        for l in lines:
+            f.write('    "%s\\n" \\\n' % l)
+        f.write('    ""\n')
+        clob_gv = ['v%d' % r for r in list(range(204, 212)) + list(range(220, 240)) + [248]]
+        clob_gv += ['s%d' % r for r in (64, 65, 66, 74, 75)] + ['scc', 'memory']
+        f.write('#define TAI_GV_ROWLOOP_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob_gv))
         clob_b = ['v%d' % r for r in list(range(220, 240)) + [243, 244, 245, 246, 247, 248]]
         clob_b += ['s%d' % r for r in range(64, 71)] + ['scc', 'memory']
         f.write('#define TAI_FWD_ROWLOOP_B_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob_b))

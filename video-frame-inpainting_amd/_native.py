@@ -70,6 +70,8 @@ def lib():
     L.tai_bias_act_inplace.restype = I
     L.tai_sepconv_set_forward_variant.argtypes = [I]
     L.tai_sepconv_set_forward_variant.restype = I
+    L.tai_sepconv_set_grad_taps_variant.argtypes = [I]
+    L.tai_sepconv_set_grad_taps_variant.restype = I
     L.tai_sepconv_set_grad_input_variant.argtypes = [I]
     L.tai_sepconv_set_grad_input_variant.restype = I
     L.tai_sepconv_forward_bytes.argtypes = [I] * 5

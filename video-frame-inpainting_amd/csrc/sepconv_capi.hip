@@ -21,7 +21,8 @@ namespace {
 
 thread_local char g_err[256] = "";
 int g_fwd_variant = 0;
-int g_gi_variant = 0;   // 0 automatic (LDS row-scatter when tileable), 1 force the gather kernel
+int g_gi_variant = 0;
+int g_vh_variant = 0;   // 0 automatic (fused asm kernel for C == 1 when both gradients are wanted), 1 HIP kernels   // 0 automatic (LDS row-scatter when tileable), 1 force the gather kernel
 
 int fail(int code, const char* fmt, const char* what) {
     std::snprintf(g_err, sizeof(g_err), fmt, what);
@@ -199,6 +200,12 @@ int tai_sepconv_set_forward_variant(int variant) {
     return prev;
 }
 
+int tai_sepconv_set_grad_taps_variant(int variant) {
+    const int prev = g_vh_variant;
+    g_vh_variant = variant;
+    return prev;
+}
+
 int tai_sepconv_set_grad_input_variant(int variant) {
     const int prev = g_gi_variant;
     g_gi_variant = variant;
@@ -314,7 +321,17 @@ int tai_sepconv_backward(const float* grad_output, const float* input, const flo
 
     // gV then gH then gI: the reference's launch order (SeparableConvolution_kernel.cu:201-239).
     const bool tileable = (ks == 51) && (W % 4 == 0) && (C == 1 || C == 3);
-    if (tileable) {
+    if (tileable && C == 1 && grad_vertical && grad_horizontal && g_vh_variant != 1) {
+        // both tap gradients of a single-channel frame in one launch of the hand-scheduled wave types
+        const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W, tiles_y = (H + 7) / 8;
+        const size_t patch = (size_t)(8 + 50) * 180 * sizeof(float);
+        const size_t lds = ((patch + 1023) & ~(size_t)1023) + (size_t)8 * TAI_FWD_ROWLOOP_RING_SLOTS * 1024;
+        auto kern = bwd::sepconv_grad_vh_ab;
+        if (int rc = allow_lds(kern, lds)) return rc;
+        hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(512), lds, s, grad_output, input, vertical, horizontal,
+                           grad_vertical, grad_horizontal, H, W, tiles_x, tiles_y);
+        if (int rc = check_launch("sepconv_grad_vh_ab")) return rc;
+    } else if (tileable) {
         const int rc = (C == 1) ? launch_grad_vh_tiled<51, 1>(grad_output, input, vertical, horizontal,
                                                                 grad_vertical, grad_horizontal, B, H, W, s)
                                 : launch_grad_vh_tiled<51, 3>(grad_output, input, vertical, horizontal,
