@@ -73,7 +73,8 @@ int tai_bias_act_inplace(float* x, const float* bias, int N, int C, int HW, int 
  *   5 = as 4 with the row loop hand-scheduled in gfx950 assembly (v planes by LDS-DMA), 6 = as 5 with
  *       the tap loads of half the waves deferred behind a workgroup barrier, 7-9 = 16-row tiles (8 waves),
  *   10-13 = 8-wave workgroups mixing "taps first" (type A) and "taps last" (type B) waves on every SIMD;
- *       13 (default for C == 1) adds 16-byte patch staging and alternating wave priorities,
+ *       13 adds 16-byte patch staging and alternating wave priorities, 16 (default for C == 1) = 13 with each XCD
+ *       given a contiguous eighth of the tile list,
  *   14/15 = type-A waves that load their taps once and run the row loop once per channel (8- / 4-wave workgroups;
  *       15 is the default for C > 1).
  *   Values >= 100 are timing experiments and may produce wrong results.

@@ -232,7 +232,7 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
     int variant = g_fwd_variant;
     const bool tileable = (ks == 51) && (W % 4 == 0);
     // default: mixed type-A / type-B hand-scheduled kernel for single-channel frames; taps-once channel loop otherwise
-    if (variant == 0) variant = !tileable ? 1 : (C == 1 ? 13 : 15);
+    if (variant == 0) variant = !tileable ? 1 : (C == 1 ? 16 : 15);
     if (variant != 1 && !tileable)
         return fail(TAI_SEPCONV_EINVAL, "%s", "tiled forward variants need ks == 51 and W % 4 == 0");
     switch (variant) {
@@ -257,6 +257,7 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 108: return fwd_ab_all_channels<3, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 106: return fwd_ab_all_channels<0, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 107: return fwd_ab_all_channels<2, 3>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 16: return fwd_ab_all_channels<4>(input, vertical, horizontal, output, B, C, H, W, s);
         case 14: return fwd_asm_channel_loop<8>(input, vertical, horizontal, output, B, C, H, W, s);
         case 15: return fwd_asm_channel_loop<4>(input, vertical, horizontal, output, B, C, H, W, s);
         case 111: return fwd_asm_all_channels<false, 0, 8, 2>(input, vertical, horizontal, output, B, C, H, W, s);
