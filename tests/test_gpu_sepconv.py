@@ -175,6 +175,19 @@ def test_partial_gradients_and_error_reporting():
     assert L.tai_sepconv_forward(di.data_ptr(), dv.data_ptr(), dh.data_ptr(), di.data_ptr(), 0, 1, 8, 8, 51, None) == -1
 
 
+def test_index_space_limit_is_rejected_before_any_launch():
+    # the kernels decode flat 32-bit indices like the reference (SeparableConvolution_kernel.cu:35-38): >= 2^31 elements
+    # in any operand is refused up front instead of wrapping around
+    L = _native.lib()
+    t = torch.zeros(16, device=DEV)
+    p = t.data_ptr()
+    assert L.tai_sepconv_forward(p, p, p, p, 4096, 1, 1024, 1024, 51, None) == -1        # B*ks*H*W = 2.2e11
+    assert b'dimension' in L.tai_sepconv_last_error()
+    assert L.tai_sepconv_backward(p, p, p, p, p, p, p, 1, 1, 30000, 30000, 51, None) == -1
+    assert L.tai_sepconv_forward(p, p, p, p, 1, 1, 8, 8, 0, None) == -1                    # ks <= 0
+    torch.cuda.synchronize()
+
+
 def test_runs_on_a_side_stream_and_inside_a_graph():
     inp, v, h, _ = _case(2, 1, 16, 128, 51, 6)
     di, dv, dh = inp.to(DEV), v.to(DEV), h.to(DEV)
