@@ -69,9 +69,9 @@ def test_direction_fusion_and_graph_replay_change_nothing():
     P, Fo = clips[:, :3], clips[:, 5:]
     with torch.no_grad():
         fused = {k: v.clone() for k, v in m(2, P, Fo).items()}
-        m.fuse_directions = False
+        m.fuse_directions = m.batch_time_steps = False
         split = m(2, P, Fo)
-        m.fuse_directions = True
+        m.fuse_directions = m.batch_time_steps = True
     for k in KEYS:
         assert float((fused[k] - split[k]).abs().max()) <= 2e-5, k
     g = GraphedForward(m, 2, P, Fo)

@@ -120,6 +120,7 @@ def test_tai_forward_control_flow_matches_reference_run(golden_dir, tag, fuse):
     m = vfi.TAIFillInModel(4, int(z['c_dim'][0]), 3, int(z['ks'][0]), num_block=int(z['num_block'][0]), kf_dim=2)
     m.load_state_dict(sd)                       # the reference's key schema loads unchanged (strict)
     m.fuse_directions = fuse
+    m.batch_time_steps = fuse            # (False, False) is the reference's literal per-direction, per-step schedule
     m.kernelnet.separableConvolution = _oracle_sepconv
     with torch.no_grad():
         out = m(int(z['T'][0]), torch.from_numpy(z['P']), torch.from_numpy(z['F']))
