@@ -66,6 +66,18 @@ int tai_upsample_bilinear2x_forward(const float* input, float* output, int plane
  * pairs, src/models/mcnet/mcnet.py:28-43,79-102,137-144,172-176,203-225; src/models/tai/tai.py:256-261). */
 int tai_bias_act_inplace(float* x, const float* bias, int N, int C, int HW, int act, void* hip_stream);
 
+/* Direct "same"-padded stride-1 convolutions for the generator's thin layers, bias and activation fused (act: 0 none,
+ * 1 ReLU, 2 tanh), fp32 NCHW contiguous, W % 4 == 0:
+ *   tai_conv_cin1_forward       x [N,1,H,W], weight [Co,1,k,k] (k in {3,5}), y [N,Co,H,W]   (nn.Conv2d(1, gf, 5, padding=2)
+ *                               + ReLU, src/models/mcnet/mcnet.py:28-31; nn.Conv2d(c_dim=1, gf, 3, padding=1) + ReLU, :79-81)
+ *   tai_conv_cout1_3x3_forward  x [N,Ci,H,W], weight [1,Ci,3,3] in conv2d layout, y [N,1,H,W]
+ *                               (nn.ConvTranspose2d(gf, c_dim=1, 3, padding=1) + Tanh, mcnet.py:223-224, after the
+ *                               transpose-and-flip that turns it into a direct convolution). */
+int tai_conv_cin1_forward(const float* x, const float* weight, const float* bias, float* y, int N, int Co, int H, int W,
+                          int k, int act, void* hip_stream);
+int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float* bias, float* y, int N, int Ci, int H,
+                               int W, int act, void* hip_stream);
+
 /* Selects a kernel variant for tai_sepconv_forward (benchmarking / tests):
  *   0 = automatic (default), 1 = generic one-thread-per-output kernel (any shape),
  *   2 = LDS-tiled, whole tap set register-resident, 3 = LDS-tiled, taps split over half-waves,

@@ -25,6 +25,24 @@ def conv_bias_act(x, weight, bias, padding, act):
     if not fused:
         y = F.conv2d(x, weight, bias, stride=1, padding=padding)
         return torch.relu(y) if act == 'relu' else (torch.tanh(y) if act == 'tanh' else y)
+    Co, Ci, kh, kw = weight.shape
+    N, _, H, W = x.shape
+    thin_in = Ci == 1 and kh == kw and kh in (3, 5) and padding == kh // 2 and W % 4 == 0 and act in (None, 'relu') and Co >= 16
+    thin_out = Co == 1 and kh == kw == 3 and padding == 1 and W % 4 == 0 and Ci >= 16
+    if thin_in or thin_out:
+        # one input or one output channel: no GEMM in it, a stream of the wide tensor (csrc/thin_conv.hip.inc)
+        L = _native.lib()
+        x, weight = x.contiguous(), weight.contiguous()
+        y = torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            if thin_in:
+                _native.check(L.tai_conv_cin1_forward(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Co,
+                                                      H, W, kh, _ACT[act], stream), 'tai_conv_cin1_forward')
+            else:
+                _native.check(L.tai_conv_cout1_3x3_forward(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), N,
+                                                           Ci, H, W, _ACT[act], stream), 'tai_conv_cout1_3x3_forward')
+        return y
     y = F.conv2d(x, weight, None, stride=1, padding=padding)
     if not y.is_contiguous():
         y = y.contiguous()

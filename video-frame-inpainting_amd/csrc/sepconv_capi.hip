@@ -16,6 +16,7 @@
 #include "sepconv_bwd.hip.inc"
 #include "upsample.hip.inc"
 #include "bias_act.hip.inc"
+#include "thin_conv.hip.inc"
 
 namespace {
 
@@ -288,6 +289,39 @@ int tai_bias_act_inplace(float* x, const float* bias, int N, int C, int HW, int 
     else { TAI_LAUNCH_BACT(bact::ACT_NONE); }
 #undef TAI_LAUNCH_BACT
     return check_launch("bias_act");
+}
+
+int tai_conv_cin1_forward(const float* x, const float* weight, const float* bias, float* y, int N, int Co, int H, int W,
+                          int k, int act, void* hip_stream) {
+    g_err[0] = 0;
+    if (!x || !weight || !bias || !y) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (N <= 0 || Co <= 0 || H <= 0 || W <= 0 || W % 4 != 0 || (k != 3 && k != 5) || act < 0 || act > 1)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv_cin1: needs W % 4 == 0, k in {3, 5}, act in {0, 1}");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const long long work = (long long)N * H * (W / 4);
+    const int blocks = (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192);
+#define TAI_LAUNCH_CIN1(K, A) hipLaunchKernelGGL((thin::conv_cin1<K, A>), dim3(blocks), dim3(256), 0, s, x, weight, bias, y, N, Co, H, W)
+    if (k == 3 && act == 0) TAI_LAUNCH_CIN1(3, 0);
+    else if (k == 3) TAI_LAUNCH_CIN1(3, 1);
+    else if (act == 0) TAI_LAUNCH_CIN1(5, 0);
+    else TAI_LAUNCH_CIN1(5, 1);
+#undef TAI_LAUNCH_CIN1
+    return check_launch("conv_cin1");
+}
+
+int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float* bias, float* y, int N, int Ci, int H,
+                               int W, int act, void* hip_stream) {
+    g_err[0] = 0;
+    if (!x || !weight || !bias || !y) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (N <= 0 || Ci <= 0 || H <= 0 || W <= 0 || W % 4 != 0 || act < 0 || act > 2)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv_cout1: needs W % 4 == 0, act in {0, 1, 2}");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const long long work = (long long)N * H * (W / 4);
+    const int blocks = (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192);
+    if (act == 0) hipLaunchKernelGGL(thin::conv_cout1_3x3<0>, dim3(blocks), dim3(256), 0, s, x, weight, bias, y, N, Ci, H, W);
+    else if (act == 1) hipLaunchKernelGGL(thin::conv_cout1_3x3<1>, dim3(blocks), dim3(256), 0, s, x, weight, bias, y, N, Ci, H, W);
+    else hipLaunchKernelGGL(thin::conv_cout1_3x3<2>, dim3(blocks), dim3(256), 0, s, x, weight, bias, y, N, Ci, H, W);
+    return check_launch("conv_cout1_3x3");
 }
 
 int tai_upsample_bilinear2x_forward(const float* input, float* output, int planes, int H, int W, void* hip_stream) {
