@@ -78,6 +78,18 @@ int tai_conv_cin1_forward(const float* x, const float* weight, const float* bias
 int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float* bias, float* y, int N, int Ci, int H,
                                int W, int act, void* hip_stream);
 
+/* 3x3 stride-1 zero-padded ("same") convolution + bias + activation, fp32 NCHW contiguous, H and W even, computed as
+ * Winograd F(2x2,3x3) on the fp32 MFMA pipe.  Replaces nn.Conv2d(C, K, 3, padding=1) [+ ReLU] of the generator and the
+ * kernel network (src/models/mcnet/mcnet.py:79-118,131-152,165-170,271; src/models/tai/tai.py:248-286) and, after the
+ * transpose-and-flip of the weight, nn.ConvTranspose2d(C, K, 3, padding=1) of DecCnn (mcnet.py:198-224).
+ *   tai_conv3x3_wino_weight_floats      number of floats of the transformed-weight buffer U for a [K,C,3,3] weight
+ *   tai_conv3x3_wino_transform_weights  weight [K,C,3,3] -> U (once per weight; U is what the forward reads)
+ *   tai_conv3x3_wino_forward            x [N,C,H,W], U, bias [K] -> y [N,K,H,W]; act: 0 none, 1 ReLU, 2 tanh */
+long long tai_conv3x3_wino_weight_floats(int K, int C);
+int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int C, void* hip_stream);
+int tai_conv3x3_wino_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W,
+                             int act, void* hip_stream);
+
 /* Selects a kernel variant for tai_sepconv_forward (benchmarking / tests):
  *   0 = automatic (default), 1 = generic one-thread-per-output kernel (any shape),
  *   2 = LDS-tiled, whole tap set register-resident, 3 = LDS-tiled, taps split over half-waves,

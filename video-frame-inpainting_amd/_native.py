@@ -14,7 +14,7 @@ _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, 'libtai_sepconv.so')
 HEADER = os.path.join(_ROOT, 'include', 'tai_sepconv.h')
 SOURCES = [os.path.join(_PKG, 'csrc', f) for f in
-           ('sepconv_capi.hip', 'sepconv_fwd.hip.inc', 'sepconv_bwd.hip.inc', 'sepconv_fwd_rowloop.inc', 'upsample.hip.inc', 'bias_act.hip.inc', 'thin_conv.hip.inc')]
+           ('sepconv_capi.hip', 'sepconv_fwd.hip.inc', 'sepconv_bwd.hip.inc', 'sepconv_fwd_rowloop.inc', 'upsample.hip.inc', 'bias_act.hip.inc', 'thin_conv.hip.inc', 'wino_conv.hip.inc')]
 
 _lib = None
 
@@ -66,6 +66,12 @@ def lib():
     L.tai_sepconv_backward.restype = I
     L.tai_upsample_bilinear2x_forward.argtypes = [P, P, I, I, I, V]
     L.tai_upsample_bilinear2x_forward.restype = I
+    L.tai_conv3x3_wino_weight_floats.argtypes = [I, I]
+    L.tai_conv3x3_wino_weight_floats.restype = ctypes.c_longlong
+    L.tai_conv3x3_wino_transform_weights.argtypes = [P, P, I, I, V]
+    L.tai_conv3x3_wino_transform_weights.restype = I
+    L.tai_conv3x3_wino_forward.argtypes = [P, P, P, P, I, I, I, I, I, I, V]
+    L.tai_conv3x3_wino_forward.restype = I
     L.tai_conv_cin1_forward.argtypes = [P, P, P, P, I, I, I, I, I, I, V]
     L.tai_conv_cin1_forward.restype = I
     L.tai_conv_cout1_3x3_forward.argtypes = [P, P, P, P, I, I, I, I, I, V]

@@ -17,6 +17,7 @@
 #include "upsample.hip.inc"
 #include "bias_act.hip.inc"
 #include "thin_conv.hip.inc"
+#include "wino_conv.hip.inc"
 
 namespace {
 
@@ -322,6 +323,48 @@ int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float*
     else if (act == 1) hipLaunchKernelGGL(thin::conv_cout1_3x3<1>, dim3(blocks), dim3(256), 0, s, x, weight, bias, y, N, Ci, H, W);
     else hipLaunchKernelGGL(thin::conv_cout1_3x3<2>, dim3(blocks), dim3(256), 0, s, x, weight, bias, y, N, Ci, H, W);
     return check_launch("conv_cout1_3x3");
+}
+
+long long tai_conv3x3_wino_weight_floats(int K, int C) {
+    if (K <= 0 || C <= 0) return 0;
+    const long long Kpad = (K + wino::TM - 1) / wino::TM * wino::TM, Cpad = (C + wino::KC - 1) / wino::KC * wino::KC;
+    return 16 * Kpad * Cpad;
+}
+
+int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int C, void* hip_stream) {
+    g_err[0] = 0;
+    if (!weight || !U || K <= 0 || C <= 0) return fail(TAI_SEPCONV_EINVAL, "%s", "wino transform_weights: bad argument");
+    const int Kpad = (K + wino::TM - 1) / wino::TM * wino::TM, Cpad = (C + wino::KC - 1) / wino::KC * wino::KC;
+    const long long total = (long long)Kpad * Cpad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wino::transform_weights, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), weight, U, K,
+                       C, Kpad, Cpad);
+    return check_launch("wino_transform_weights");
+}
+
+int tai_conv3x3_wino_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W,
+                             int act, void* hip_stream) {
+    g_err[0] = 0;
+    if (!x || !U || !bias || !y) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2 || act < 0 || act > 2)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: needs even H and W, act in {0, 1, 2}");
+    if ((long long)N * (C > K ? C : K) * H * W >= 0x7fffffffLL) return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: tensor too large");
+    const int Kpad = (K + wino::TM - 1) / wino::TM * wino::TM, Cpad = (C + wino::KC - 1) / wino::KC * wino::KC;
+    const int kblocks = Kpad / wino::TM, nchunks = Cpad / wino::KC;
+    const long long tiles = (long long)N * (H / 2) * (W / 2);
+    const long long tblocks = (tiles + wino::TN - 1) / wino::TN;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+#define TAI_LAUNCH_WINO(A)                                                                                             \
+    do {                                                                                                               \
+        if (int rc = allow_lds(wino::conv3x3<A>, wino::LDS_BYTES)) return rc;                                          \
+        hipLaunchKernelGGL(wino::conv3x3<A>, dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::LDS_BYTES, s, x, U, \
+                           bias, y, N, C, K, H, W, Kpad, nchunks, kblocks);                                            \
+    } while (0)
+    if (act == 0) TAI_LAUNCH_WINO(0);
+    else if (act == 1) TAI_LAUNCH_WINO(1);
+    else TAI_LAUNCH_WINO(2);
+#undef TAI_LAUNCH_WINO
+    return check_launch("conv3x3_wino");
 }
 
 int tai_upsample_bilinear2x_forward(const float* input, float* output, int planes, int H, int W, void* hip_stream) {
