@@ -1,0 +1,108 @@
+"""Winograd F(2x2,3x3) MFMA convolution (csrc/wino_conv.hip.inc) against an fp64 convolution of the same operands.
+Reference layers: nn.Conv2d(C, K, 3, padding=1) (+ReLU) of src/models/mcnet/mcnet.py:79-118,131-152,165-170,271 and
+src/models/tai/tai.py:248-286; nn.ConvTranspose2d(C, K, 3, padding=1) of mcnet.py:198-224."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _wino(x, w, b, act):
+    from video_frame_inpainting_amd import _native
+    L = _native.lib()
+    N, C, H, W = x.shape
+    K = w.shape[0]
+    U = torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), device='cuda')
+    s = torch.cuda.current_stream().cuda_stream
+    _native.check(L.tai_conv3x3_wino_transform_weights(w.data_ptr(), U.data_ptr(), K, C, s), 'transform')
+    y = torch.full((N, K, H, W), float('nan'), device='cuda')
+    _native.check(L.tai_conv3x3_wino_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), N, C, K, H, W,
+                                             {None: 0, 'relu': 1, 'tanh': 2}[act], s), 'forward')
+    return y
+
+
+def _check(x, w, b, act, tol=4e-6):
+    got = _wino(x, w, b, act)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = torch.relu(ref) if act == 'relu' else (torch.tanh(ref) if act == 'tanh' else ref)
+    # fp32 Winograd: the error scales with the sum of |terms| of the dot product (the transforms add and subtract
+    # neighbouring inputs and weights before multiplying)
+    mag = F.conv2d(x.double().abs(), w.double().abs(), b.double().abs(), padding=1)
+    err = ((got.double() - ref).abs() / (1 + mag)).max().item()
+    assert torch.isfinite(got).all()
+    assert err <= tol, err
+
+
+# (N, C, K, H, W): channel counts that are not multiples of the 8-channel chunk or the 64-channel block, tile counts
+# that are not multiples of the 64-tile block, tiles that straddle images, 2x2 and 4x4 images, the bi-TAI shapes
+SHAPES = [(1, 8, 8, 2, 2), (2, 8, 8, 8, 8), (3, 20, 51, 12, 20), (1, 65, 64, 16, 16), (5, 13, 70, 6, 10), (7, 9, 3, 4, 4),
+          (2, 64, 64, 128, 128), (2, 51, 51, 128, 128), (4, 512, 128, 16, 16), (3, 128, 130, 32, 32)]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('act', [None, 'relu', 'tanh'])
+def test_wino_matches_fp64_conv(shape, act):
+    N, C, K, H, W = shape
+    g = torch.Generator().manual_seed(N * 1000 + C)
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    w = (torch.randn(K, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda()
+    b = torch.randn(K, generator=g).cuda()
+    _check(x, w, b, act)
+
+
+def test_wino_exact_on_small_integers():
+    # integer-valued inputs and weights whose transforms stay exact in fp32: the result must be the exact convolution
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-4, 5, (2, 16, 12, 12), generator=g).float().cuda()
+    w = (torch.randint(-2, 3, (32, 16, 3, 3), generator=g) * 4).float().cuda()     # multiples of 4: G g G^T exact
+    b = torch.randint(-3, 4, (32,), generator=g).float().cuda()
+    got = _wino(x, w, b, None)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    assert torch.equal(got.double(), ref)
+
+
+def test_wino_zero_padding_not_replication():
+    x = torch.ones(1, 8, 4, 4, device='cuda')
+    w = torch.ones(8, 8, 3, 3, device='cuda')
+    b = torch.zeros(8, device='cuda')
+    got = _wino(x, w, b, None)
+    assert got[0, 0, 0, 0].item() == 32.0 and got[0, 0, 0, 1].item() == 48.0 and got[0, 0, 1, 1].item() == 72.0
+
+
+def test_conv_bias_act_routes_to_wino_and_tracks_weight_updates():
+    from video_frame_inpainting_amd import conv_ops
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1).cuda()
+    x = torch.randn(16, 64, 64, 64, device='cuda')
+    with torch.no_grad():
+        y1 = conv_ops.conv_bias_act(x, conv.weight, conv.bias, 1, 'relu')
+        assert ('wino', False) in conv.weight._tai_derived                      # the MFMA kernel ran, not MIOpen
+        assert (y1 - torch.relu(conv(x))).abs().max().item() <= 5e-5
+        conv.weight.mul_(2.0)                                                     # in-place update -> U is rebuilt
+        y2 = conv_ops.conv_bias_act(x, conv.weight, conv.bias, 1, 'relu')
+        assert (y2 - torch.relu(conv(x))).abs().max().item() <= 1e-4
+
+
+def test_transposed_conv_through_wino():
+    from video_frame_inpainting_amd import conv_ops
+    layer = torch.nn.ConvTranspose2d(128, 64, 3, padding=1).cuda()
+    x = torch.randn(16, 128, 64, 64, device='cuda')
+    with torch.no_grad():
+        got = conv_ops.conv_bias_act(x, layer.weight, layer.bias, 1, 'relu', transposed=True)
+        assert ('wino', True) in layer.weight._tai_derived
+        ref = torch.relu(layer(x))
+    assert (got - ref).abs().max().item() <= 5e-5
+
+
+def test_wino_rejects_bad_arguments():
+    from video_frame_inpainting_amd import _native
+    L = _native.lib()
+    x = torch.zeros(1, 8, 5, 4, device='cuda')
+    U = torch.zeros(L.tai_conv3x3_wino_weight_floats(8, 8), device='cuda')
+    b = torch.zeros(8, device='cuda')
+    y = torch.zeros(1, 8, 5, 4, device='cuda')
+    assert L.tai_conv3x3_wino_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 8, 8, 5, 4, 0, None) != 0
+    assert b'even' in L.tai_sepconv_last_error()
+    assert L.tai_conv3x3_wino_forward(None, U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 8, 8, 4, 4, 0, None) != 0
+    assert L.tai_conv3x3_wino_weight_floats(64, 64) == 16 * 64 * 64
+    assert L.tai_conv3x3_wino_weight_floats(51, 65) == 16 * 64 * 72

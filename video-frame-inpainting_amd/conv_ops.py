@@ -18,37 +18,88 @@ def _finish(y, bias, act):
     return y + bias.view(1, -1, 1, 1) if bias is not None else y
 
 
-def conv_bias_act(x, weight, bias, padding, act):
-    """act(conv2d(x, weight, stride 1, padding) + bias), act in {None, 'relu', 'tanh'}."""
+def _as_conv_weight(weight, transposed):
+    # ConvTranspose2d(cin, cout, 3, stride 1, padding 1)  ==  conv2d with weight[o, i, ky, kx] = wt[i, o, 2-ky, 2-kx]
+    return weight.transpose(0, 1).flip(2, 3) if transposed else weight
+
+
+def _cached(weight, tag, make):
+    """Derived form of a weight (Winograd-domain U, direct-conv layout of a transposed conv), kept on the tensor object
+    and rebuilt when the weight is modified in place (optimizer step, load_state_dict)."""
+    cache = getattr(weight, '_tai_derived', None)
+    if cache is None:
+        cache = {}
+        weight._tai_derived = cache
+    hit = cache.get(tag)
+    if hit is None or hit[0] != weight._version or hit[1] != weight.data_ptr():
+        hit = (weight._version, weight.data_ptr(), make())
+        cache[tag] = hit
+    return hit[2]
+
+
+def _wino_weights(weight, transposed):
+    def make():
+        w = _as_conv_weight(weight.detach(), transposed).contiguous()
+        K, C = w.shape[0], w.shape[1]
+        L = _native.lib()
+        U = torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _native.check(L.tai_conv3x3_wino_transform_weights(w.data_ptr(), U.data_ptr(), K, C,
+                                                               torch.cuda.current_stream(w.device).cuda_stream),
+                          'tai_conv3x3_wino_transform_weights')
+        return U
+    return _cached(weight, ('wino', transposed), make)
+
+
+WINO_MIN_WORKGROUPS = 192      # below this the 64x64-tile kernel leaves most of the 256 CUs idle; MIOpen takes those
+
+
+def conv_bias_act(x, weight, bias, padding, act, transposed=False):
+    """act(conv2d(x, weight, stride 1, padding) + bias), act in {None, 'relu', 'tanh'}.  ``transposed``: ``weight`` is
+    the [in, out, 3, 3] weight of a ConvTranspose2d(k 3, stride 1, padding 1), which is the same convolution with the
+    weight transposed and flipped."""
     fused = (x.is_cuda and x.dtype == torch.float32 and bias is not None
              and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or bias.requires_grad)))
     if not fused:
-        y = F.conv2d(x, weight, bias, stride=1, padding=padding)
+        y = F.conv2d(x, _as_conv_weight(weight, transposed), bias, stride=1, padding=padding)
         return torch.relu(y) if act == 'relu' else (torch.tanh(y) if act == 'tanh' else y)
-    Co, Ci, kh, kw = weight.shape
+    kh, kw = weight.shape[2], weight.shape[3]
+    Co, Ci = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
     N, _, H, W = x.shape
+    L = _native.lib()
+    stream = torch.cuda.current_stream(x.device).cuda_stream
     thin_in = Ci == 1 and kh == kw and kh in (3, 5) and padding == kh // 2 and W % 4 == 0 and act in (None, 'relu') and Co >= 16
     thin_out = Co == 1 and kh == kw == 3 and padding == 1 and W % 4 == 0 and Ci >= 16
     if thin_in or thin_out:
         # one input or one output channel: no GEMM in it, a stream of the wide tensor (csrc/thin_conv.hip.inc)
-        L = _native.lib()
-        x, weight = x.contiguous(), weight.contiguous()
+        x = x.contiguous()
+        w = _cached(weight, ('direct', transposed), lambda: _as_conv_weight(weight.detach(), transposed).contiguous())
         y = torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
         with torch.cuda.device(x.device):
             if thin_in:
-                _native.check(L.tai_conv_cin1_forward(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Co,
+                _native.check(L.tai_conv_cin1_forward(x.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Co,
                                                       H, W, kh, _ACT[act], stream), 'tai_conv_cin1_forward')
             else:
-                _native.check(L.tai_conv_cout1_3x3_forward(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), N,
+                _native.check(L.tai_conv_cout1_3x3_forward(x.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr(), N,
                                                            Ci, H, W, _ACT[act], stream), 'tai_conv_cout1_3x3_forward')
         return y
-    y = F.conv2d(x, weight, None, stride=1, padding=padding)
+    if (kh == kw == 3 and padding == 1 and H % 2 == 0 and W % 2 == 0 and Ci >= 8 and N * max(Ci, Co) * H * W < 2 ** 30
+            and ((N * (H // 2) * (W // 2) + 63) // 64) * ((Co + 63) // 64) >= WINO_MIN_WORKGROUPS):
+        # Winograd F(2x2,3x3) on the fp32 MFMA pipe (csrc/wino_conv.hip.inc)
+        x = x.contiguous()
+        U = _wino_weights(weight, transposed)
+        y = torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _native.check(L.tai_conv3x3_wino_forward(x.data_ptr(), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci, Co,
+                                                     H, W, _ACT[act], stream), 'tai_conv3x3_wino_forward')
+        return y
+    w = _cached(weight, ('direct', transposed), lambda: _as_conv_weight(weight.detach(), transposed).contiguous()) \
+        if transposed else weight
+    y = F.conv2d(x, w, None, stride=1, padding=padding)
     if not y.is_contiguous():
         y = y.contiguous()
     N, C, H, W = y.shape
     with torch.cuda.device(y.device):
-        _native.check(_native.lib().tai_bias_act_inplace(y.data_ptr(), bias.data_ptr(), N, C, H * W, _ACT[act],
-                                                         torch.cuda.current_stream(y.device).cuda_stream),
+        _native.check(L.tai_bias_act_inplace(y.data_ptr(), bias.data_ptr(), N, C, H * W, _ACT[act], stream),
                       'tai_bias_act_inplace')
     return y

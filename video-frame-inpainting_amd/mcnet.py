@@ -48,8 +48,7 @@ def _conv_relu_chain(x, convs, last_act='relu'):
 
 def _convt3x3_as_conv(x, layer, act):
     # ConvTranspose2d(cin, cout, 3, stride 1, padding 1)  ==  conv2d with weight[o, i, ky, kx] = wt[i, o, 2-ky, 2-kx]
-    w = layer.weight.transpose(0, 1).flip(2, 3)
-    return conv_bias_act(x, w, layer.bias, 1, act)
+    return conv_bias_act(x, layer.weight, layer.bias, 1, act, transposed=True)
 
 
 def unpool2x_add(x, res):
