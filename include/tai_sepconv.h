@@ -89,6 +89,10 @@ long long tai_conv3x3_wino_weight_floats(int K, int C);
 int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int C, void* hip_stream);
 int tai_conv3x3_wino_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W,
                              int act, void* hip_stream);
+/* Diagnostics: the same launch with ReLU, every workgroup also writes shader-clock stamps to stamps[64 * workgroup + i]:
+ * i = 0 entry, 1 prologue done, 2 channel loop done, 3 end, 4 + c end of chunk c (c < 60).  stamps: 64 * workgroups int64. */
+int tai_conv3x3_wino_forward_timeline(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H,
+                                      int W, long long* stamps, void* hip_stream);
 
 /* Selects a kernel variant for tai_sepconv_forward (benchmarking / tests):
  *   0 = automatic (default), 1 = generic one-thread-per-output kernel (any shape),

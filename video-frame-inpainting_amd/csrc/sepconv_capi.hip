@@ -342,8 +342,22 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
     return check_launch("wino_transform_weights");
 }
 
+static int wino_forward_impl(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W,
+                             int act, void* hip_stream, long long* stamps);
+
 int tai_conv3x3_wino_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W,
                              int act, void* hip_stream) {
+    return wino_forward_impl(x, U, bias, y, N, C, K, H, W, act, hip_stream, nullptr);
+}
+
+int tai_conv3x3_wino_forward_timeline(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H,
+                                      int W, long long* stamps, void* hip_stream) {
+    if (!stamps) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    return wino_forward_impl(x, U, bias, y, N, C, K, H, W, 1, hip_stream, stamps);
+}
+
+static int wino_forward_impl(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W,
+                             int act, void* hip_stream, long long* stamps) {
     g_err[0] = 0;
     if (!x || !U || !bias || !y) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
     if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2 || act < 0 || act > 2)
@@ -354,15 +368,16 @@ int tai_conv3x3_wino_forward(const float* x, const float* U, const float* bias, 
     const long long tiles = (long long)N * (H / 2) * (W / 2);
     const long long tblocks = (tiles + wino::TN - 1) / wino::TN;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-#define TAI_LAUNCH_WINO(A)                                                                                             \
+#define TAI_LAUNCH_WINO(A, D)                                                                                          \
     do {                                                                                                               \
-        if (int rc = allow_lds(wino::conv3x3<A>, wino::LDS_BYTES)) return rc;                                          \
-        hipLaunchKernelGGL(wino::conv3x3<A>, dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::LDS_BYTES, s, x, U, \
-                           bias, y, N, C, K, H, W, Kpad, nchunks, kblocks);                                            \
+        if (int rc = allow_lds(wino::conv3x3<A, D>, wino::LDS_BYTES)) return rc;                                       \
+        hipLaunchKernelGGL((wino::conv3x3<A, D>), dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::LDS_BYTES, s,  \
+                           x, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, stamps);                              \
     } while (0)
-    if (act == 0) TAI_LAUNCH_WINO(0);
-    else if (act == 1) TAI_LAUNCH_WINO(1);
-    else TAI_LAUNCH_WINO(2);
+    if (stamps) TAI_LAUNCH_WINO(1, 1);
+    else if (act == 0) TAI_LAUNCH_WINO(0, 0);
+    else if (act == 1) TAI_LAUNCH_WINO(1, 0);
+    else TAI_LAUNCH_WINO(2, 0);
 #undef TAI_LAUNCH_WINO
     return check_launch("conv3x3_wino");
 }
