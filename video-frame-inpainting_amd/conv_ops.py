@@ -83,7 +83,7 @@ def conv_bias_act(x, weight, bias, padding, act, transposed=False):
                 _native.check(L.tai_conv_cout1_3x3_forward(x.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr(), N,
                                                            Ci, H, W, _ACT[act], stream), 'tai_conv_cout1_3x3_forward')
         return y
-    if (kh == kw == 3 and padding == 1 and H % 2 == 0 and W % 2 == 0 and Ci >= 8 and N * max(Ci, Co) * H * W < 2 ** 30
+    if (kh == kw == 3 and padding == 1 and H % 2 == 0 and W % 2 == 0 and Ci >= 8 and N * max(Ci, Co) * H * W < 2 ** 29
             and ((N * (H // 2) * (W // 2) + 63) // 64) * ((Co + 63) // 64) >= WINO_MIN_WORKGROUPS):
         # Winograd F(2x2,3x3) on the fp32 MFMA pipe (csrc/wino_conv.hip.inc)
         x = x.contiguous()

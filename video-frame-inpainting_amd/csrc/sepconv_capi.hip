@@ -362,7 +362,8 @@ static int wino_forward_impl(const float* x, const float* U, const float* bias, 
     if (!x || !U || !bias || !y) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
     if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2 || act < 0 || act > 2)
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: needs even H and W, act in {0, 1, 2}");
-    if ((long long)N * (C > K ? C : K) * H * W >= 0x7fffffffLL) return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: tensor too large");
+    if ((long long)N * (C > K ? C : K) * H * W >= (1LL << 29))       // byte offsets stay below 2^31 (buffer addressing)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: tensor too large (2^29 elements or more)");
     const int Kpad = (K + wino::TM - 1) / wino::TM * wino::TM, Cpad = (C + wino::KC - 1) / wino::KC * wino::KC;
     const int kblocks = Kpad / wino::TM, nchunks = Cpad / wino::KC;
     const long long tiles = (long long)N * (H / 2) * (W / 2);
