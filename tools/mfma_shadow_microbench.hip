@@ -19,6 +19,21 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
             for (int q = 0; q < 4 * NV; ++q)
                 asm volatile("v_add_f32 %0, %0, %1" : "+v"(q % 8 == 0 ? r0 : q % 8 == 1 ? r1 : q % 8 == 2 ? r2 : q % 8 == 3 ? r3 : q % 8 == 4 ? r4 : q % 8 == 5 ? r5 : q % 8 == 6 ? r6 : r7) : "v"(b));
         }
+    } else if (KIND >= 5) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f p0 = {a, b}, p1 = {b, a}, p2 = {a + 1, b}, p3 = {b, a + 1};
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c0) : "v"(a), "v"(b));
+#pragma unroll
+            for (int q = 0; q < 4 * NV; ++q) {
+                if (KIND == 5) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(q % 4 == 0 ? p0 : q % 4 == 1 ? p1 : q % 4 == 2 ? p2 : p3) : "v"(p0));
+                if (KIND == 6) asm volatile("v_mul_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(q % 8 == 0 ? r0 : q % 8 == 1 ? r1 : q % 8 == 2 ? r2 : q % 8 == 3 ? r3 : q % 8 == 4 ? r4 : q % 8 == 5 ? r5 : q % 8 == 6 ? r6 : r7) : "v"(a), "v"(b));
+                if (KIND == 7) asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(q % 4 == 0 ? p0 : q % 4 == 1 ? p1 : q % 4 == 2 ? p2 : p3) : "v"(q % 4 == 0 ? p1 : q % 4 == 1 ? p2 : q % 4 == 2 ? p3 : p0));
+                if (KIND == 8) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r0) : "v"(b));
+            }
+        }
+        r0 += p0.x + p1.y + p2.x + p3.y;
     } else
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -58,6 +73,7 @@ int main() {
     run<8, 1>(out, "v_cndmask"); run<16, 1>(out, "v_cndmask");
     run<4, 2>(out, "dpp"); run<8, 2>(out, "dpp");
     run<8, 3>(out, "s_add"); run<16, 3>(out, "s_add");
+    run<4, 5>(out, "cl pk_add"); run<8, 5>(out, "cl pk_add"); run<4, 6>(out, "cl mul_dpp"); run<8, 6>(out, "cl mul_dpp"); run<4, 7>(out, "cl pk opsel"); run<8, 7>(out, "cl pk opsel"); run<4, 8>(out, "cl dep add"); run<8, 8>(out, "cl dep add");
     run<1, 4>(out, "clustered"); run<2, 4>(out, "clustered"); run<4, 4>(out, "clustered"); run<8, 4>(out, "clustered"); run<16, 4>(out, "clustered");
     run<1, 0>(out, "v_add_f32"); run<2, 0>(out, "v_add_f32");
     run<0, 0, 4>(out, "v_add_f32"); run<4, 0, 4>(out, "v_add_f32"); run<8, 0, 4>(out, "v_add_f32"); run<12, 0, 4>(out, "v_add_f32"); run<16, 0, 4>(out, "v_add_f32"); run<24, 0, 4>(out, "v_add_f32");

@@ -4,9 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from video_frame_inpainting_amd import _native
 L = _native.lib()
-shapes = [(64, 64, 64, 128, 128), (64, 256, 128, 64, 64), (64, 512, 1024, 16, 16), (32, 51, 51, 128, 128)]
-masks = [0]
+shapes = [(64, 256, 128, 64, 64)] if '--skip' in sys.argv else [(64, 64, 64, 128, 128), (64, 256, 128, 64, 64), (64, 512, 1024, 16, 16), (32, 51, 51, 128, 128)]
+masks = [0, 1, 2, 3] if '--skip' in sys.argv else [0]
 for mask in masks:
+    L.tai_conv3x3_wino_timeline_skip(mask)
+    print('skip level', mask, '(1 no transform, 2 + no V writes, 3 + no patch loads, 4 + no weight DMA)')
     for (N, C, K, H, W) in shapes:
         x = torch.randn(N, C, H, W, device='cuda'); w = torch.randn(K, C, 3, 3, device='cuda') * .05; b = torch.zeros(K, device='cuda')
         U = torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), device='cuda'); y = torch.empty(N, K, H, W, device='cuda')

@@ -344,6 +344,8 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
 
 static int wino_forward_impl(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W,
                              int act, void* hip_stream, long long* stamps);
+static int g_wino_timeline_skip = 0;   // timeline launches only: loop parts left out (wino_conv.hip.inc, SKIP)
+int tai_conv3x3_wino_timeline_skip(int level) { g_wino_timeline_skip = level; return 0; }
 
 int tai_conv3x3_wino_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W,
                              int act, void* hip_stream) {
@@ -369,13 +371,17 @@ static int wino_forward_impl(const float* x, const float* U, const float* bias, 
     const long long tiles = (long long)N * (H / 2) * (W / 2);
     const long long tblocks = (tiles + wino::TN - 1) / wino::TN;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-#define TAI_LAUNCH_WINO(A, D)                                                                                          \
+#define TAI_LAUNCH_WINO(A, D, ...)                                                                                     \
     do {                                                                                                               \
-        if (int rc = allow_lds(wino::conv3x3<A, D>, wino::LDS_BYTES)) return rc;                                       \
-        hipLaunchKernelGGL((wino::conv3x3<A, D>), dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::LDS_BYTES, s,  \
+        if (int rc = allow_lds(wino::conv3x3<A, D, ##__VA_ARGS__>, wino::LDS_BYTES)) return rc;                          \
+        hipLaunchKernelGGL((wino::conv3x3<A, D, ##__VA_ARGS__>), dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::LDS_BYTES, s,  \
                            x, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, stamps);                              \
     } while (0)
-    if (stamps) TAI_LAUNCH_WINO(1, 1);
+    if (stamps && g_wino_timeline_skip == 1) TAI_LAUNCH_WINO(1, 1, 1);
+    else if (stamps && g_wino_timeline_skip == 2) TAI_LAUNCH_WINO(1, 1, 2);
+    else if (stamps && g_wino_timeline_skip == 3) TAI_LAUNCH_WINO(1, 1, 3);
+    else if (stamps && g_wino_timeline_skip == 4) TAI_LAUNCH_WINO(1, 1, 4);
+    else if (stamps) TAI_LAUNCH_WINO(1, 1);
     else if (act == 0) TAI_LAUNCH_WINO(0, 0);
     else if (act == 1) TAI_LAUNCH_WINO(1, 0);
     else TAI_LAUNCH_WINO(2, 0);
