@@ -89,6 +89,11 @@ long long tai_conv3x3_wino_weight_floats(int K, int C);
 int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int C, void* hip_stream);
 int tai_conv3x3_wino_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W,
                              int act, void* hip_stream);
+/* The same convolution with the input given as `nparts` (1..4) contiguous [N, C / nparts, H, W] tensors, the operands of
+ * a torch.cat along the channels that is then never materialised (Residual: src/models/mcnet/mcnet.py:182, CombLayers
+ * :152, TAI.forward: src/models/tai/tai.py:188).  xs: host array of device pointers; C / nparts must be a multiple of 8. */
+int tai_conv3x3_wino_forward_parts(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N,
+                                   int C, int K, int H, int W, int act, void* hip_stream);
 /* Diagnostics: the same launch with ReLU, every workgroup also writes shader-clock stamps to stamps[64 * workgroup + i]:
  * i = 0 entry, 1 prologue done, 2 channel loop done, 3 end, 4 + c end of chunk c (c < 60).  stamps: 64 * workgroups int64. */
 int tai_conv3x3_wino_forward_timeline(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H,

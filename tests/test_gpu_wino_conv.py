@@ -106,3 +106,30 @@ def test_wino_rejects_bad_arguments():
     assert L.tai_conv3x3_wino_forward(None, U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 8, 8, 4, 4, 0, None) != 0
     assert L.tai_conv3x3_wino_weight_floats(64, 64) == 16 * 64 * 64
     assert L.tai_conv3x3_wino_weight_floats(51, 65) == 16 * 64 * 72
+
+
+@pytest.mark.parametrize('nparts', [2, 4])
+def test_wino_reads_channel_parts_without_a_cat(nparts):
+    from video_frame_inpainting_amd import conv_ops
+    g = torch.Generator().manual_seed(5)
+    parts = [torch.randn(32, 64, 32, 32, generator=g).cuda() for _ in range(nparts)]
+    conv = torch.nn.Conv2d(64 * nparts, 128, 3, padding=1).cuda()
+    with torch.no_grad():
+        got = conv_ops.conv_bias_act(tuple(parts), conv.weight, conv.bias, 1, 'relu')
+        assert ('wino', False) in conv.weight._tai_derived
+        whole = conv_ops.conv_bias_act(torch.cat(parts, dim=1), conv.weight, conv.bias, 1, 'relu')
+    assert torch.equal(got, whole)                      # same kernel, same arithmetic, same order
+
+
+def test_channel_parts_fall_back_to_cat_when_not_eligible():
+    from video_frame_inpainting_amd import conv_ops
+    a = torch.randn(2, 12, 8, 8, device='cuda')          # 12 channels per part: not a multiple of 8
+    b = torch.randn(2, 12, 8, 8, device='cuda')
+    conv = torch.nn.Conv2d(24, 16, 3, padding=1).cuda()
+    with torch.no_grad():
+        got = conv_ops.conv_bias_act((a, b), conv.weight, conv.bias, 1, None)
+        ref = conv(torch.cat((a, b), dim=1))
+    assert (got - ref).abs().max().item() <= 1e-5
+    from video_frame_inpainting_amd import _native
+    L = _native.lib()
+    assert L.tai_conv3x3_wino_forward_parts(None, 2, 0, 0, 0, 1, 16, 8, 4, 4, 0, None) != 0

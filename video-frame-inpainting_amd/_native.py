@@ -72,6 +72,8 @@ def lib():
     L.tai_conv3x3_wino_transform_weights.restype = I
     L.tai_conv3x3_wino_forward.argtypes = [P, P, P, P, I, I, I, I, I, I, V]
     L.tai_conv3x3_wino_forward.restype = I
+    L.tai_conv3x3_wino_forward_parts.argtypes = [P, I, P, P, P, I, I, I, I, I, I, V]
+    L.tai_conv3x3_wino_forward_parts.restype = I
     L.tai_conv3x3_wino_forward_timeline.argtypes = [P, P, P, P, I, I, I, I, I, P, V]
     L.tai_conv3x3_wino_forward_timeline.restype = I
     L.tai_conv_cin1_forward.argtypes = [P, P, P, P, I, I, I, I, I, I, V]

@@ -2,6 +2,8 @@
 nn.ReLU, nn.Tanh or nothing).  Inference on the GPU runs the bias-free MIOpen convolution and finishes it with the
 single-pass HIP bias+activation kernel of the C ABI (ATen would add the bias and apply the ReLU in two more full passes);
 anything that needs autograd, and CPU tensors, take the stock PyTorch ops -- same arithmetic, one rounding per add."""
+import ctypes
+
 import torch
 import torch.nn.functional as F
 
@@ -54,10 +56,37 @@ def _wino_weights(weight, transposed):
 WINO_MIN_WORKGROUPS = 192      # below this the 64x64-tile kernel leaves most of the 256 CUs idle; MIOpen takes those
 
 
+def _wino_ok(N, Ci, Co, H, W, kh, kw, padding):
+    return (kh == kw == 3 and padding == 1 and H % 2 == 0 and W % 2 == 0 and Ci >= 8 and N * max(Ci, Co) * H * W < 2 ** 29
+            and ((N * (H // 2) * (W // 2) + 63) // 64) * ((Co + 63) // 64) >= WINO_MIN_WORKGROUPS)
+
+
 def conv_bias_act(x, weight, bias, padding, act, transposed=False):
     """act(conv2d(x, weight, stride 1, padding) + bias), act in {None, 'relu', 'tanh'}.  ``transposed``: ``weight`` is
     the [in, out, 3, 3] weight of a ConvTranspose2d(k 3, stride 1, padding 1), which is the same convolution with the
-    weight transposed and flipped."""
+    weight transposed and flipped.  ``x`` may be a list of up to four tensors, meaning their concatenation along the
+    channels; the Winograd kernel reads the parts where they lie, every other path concatenates them first."""
+    if isinstance(x, (list, tuple)):
+        parts = list(x)
+        x0 = parts[0]
+        kh, kw = weight.shape[2], weight.shape[3]
+        Co, Ci = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
+        N, Cp, H, W = x0.shape
+        direct = (len(parts) <= 4 and x0.is_cuda and x0.dtype == torch.float32 and bias is not None and Cp % 8 == 0
+                  and Cp * len(parts) == Ci and all(p.shape == x0.shape and p.is_contiguous() and p.dtype == x0.dtype for p in parts)
+                  and not (torch.is_grad_enabled() and (weight.requires_grad or bias.requires_grad or any(p.requires_grad for p in parts)))
+                  and _wino_ok(N, Ci, Co, H, W, kh, kw, padding))
+        if not direct:
+            return conv_bias_act(torch.cat(parts, dim=1), weight, bias, padding, act, transposed)
+        L = _native.lib()
+        U = _wino_weights(weight, transposed)
+        y = torch.empty((N, Co, H, W), dtype=x0.dtype, device=x0.device)
+        ptrs = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+        with torch.cuda.device(x0.device):
+            _native.check(L.tai_conv3x3_wino_forward_parts(ptrs, len(parts), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci,
+                                                           Co, H, W, _ACT[act], torch.cuda.current_stream(x0.device).cuda_stream),
+                          'tai_conv3x3_wino_forward_parts')
+        return y
     fused = (x.is_cuda and x.dtype == torch.float32 and bias is not None
              and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or bias.requires_grad)))
     if not fused:
@@ -83,8 +112,7 @@ def conv_bias_act(x, weight, bias, padding, act, transposed=False):
                 _native.check(L.tai_conv_cout1_3x3_forward(x.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr(), N,
                                                            Ci, H, W, _ACT[act], stream), 'tai_conv_cout1_3x3_forward')
         return y
-    if (kh == kw == 3 and padding == 1 and H % 2 == 0 and W % 2 == 0 and Ci >= 8 and N * max(Ci, Co) * H * W < 2 ** 29
-            and ((N * (H // 2) * (W // 2) + 63) // 64) * ((Co + 63) // 64) >= WINO_MIN_WORKGROUPS):
+    if _wino_ok(N, Ci, Co, H, W, kh, kw, padding):
         # Winograd F(2x2,3x3) on the fp32 MFMA pipe (csrc/wino_conv.hip.inc)
         x = x.contiguous()
         U = _wino_weights(weight, transposed)

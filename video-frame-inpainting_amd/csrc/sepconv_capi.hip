@@ -342,26 +342,42 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
     return check_launch("wino_transform_weights");
 }
 
-static int wino_forward_impl(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W,
-                             int act, void* hip_stream, long long* stamps);
+static int wino_forward_impl(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C,
+                             int K, int H, int W, int act, void* hip_stream, long long* stamps);
 static int g_wino_timeline_skip = 0;   // timeline launches only: loop parts left out (wino_conv.hip.inc, SKIP)
 int tai_conv3x3_wino_timeline_skip(int level) { g_wino_timeline_skip = level; return 0; }
 
 int tai_conv3x3_wino_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W,
                              int act, void* hip_stream) {
-    return wino_forward_impl(x, U, bias, y, N, C, K, H, W, act, hip_stream, nullptr);
+    const float* xs[4] = {x, x, x, x};
+    return wino_forward_impl(xs, 1, U, bias, y, N, C, K, H, W, act, hip_stream, nullptr);
+}
+
+int tai_conv3x3_wino_forward_parts(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N,
+                                   int C, int K, int H, int W, int act, void* hip_stream) {
+    if (!xs || nparts < 1 || nparts > 4) return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: 1 to 4 input parts");
+    if (nparts > 1 && (C % nparts != 0 || (C / nparts) % 8 != 0))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: parts must have equal channel counts, a multiple of 8");
+    const float* p[4];
+    for (int i = 0; i < 4; ++i) {
+        p[i] = xs[i < nparts ? i : 0];
+        if (!p[i]) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    }
+    return wino_forward_impl(p, nparts, U, bias, y, N, C, K, H, W, act, hip_stream, nullptr);
 }
 
 int tai_conv3x3_wino_forward_timeline(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H,
                                       int W, long long* stamps, void* hip_stream) {
     if (!stamps) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
-    return wino_forward_impl(x, U, bias, y, N, C, K, H, W, 1, hip_stream, stamps);
+    const float* xs[4] = {x, x, x, x};
+    return wino_forward_impl(xs, 1, U, bias, y, N, C, K, H, W, 1, hip_stream, stamps);
 }
 
-static int wino_forward_impl(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W,
-                             int act, void* hip_stream, long long* stamps) {
+static int wino_forward_impl(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C,
+                             int K, int H, int W, int act, void* hip_stream, long long* stamps) {
     g_err[0] = 0;
-    if (!x || !U || !bias || !y) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (!xs[0] || !U || !bias || !y) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    const int cpart = C / nparts;
     if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2 || act < 0 || act > 2)
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: needs even H and W, act in {0, 1, 2}");
     if ((long long)N * (C > K ? C : K) * H * W >= (1LL << 29))       // byte offsets stay below 2^31 (buffer addressing)
@@ -375,7 +391,7 @@ static int wino_forward_impl(const float* x, const float* U, const float* bias, 
     do {                                                                                                               \
         if (int rc = allow_lds(wino::conv3x3<A, D, ##__VA_ARGS__>, wino::LDS_BYTES)) return rc;                          \
         hipLaunchKernelGGL((wino::conv3x3<A, D, ##__VA_ARGS__>), dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::LDS_BYTES, s,  \
-                           x, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, stamps);                              \
+                           xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, stamps);                              \
     } while (0)
     if (stamps && g_wino_timeline_skip == 1) TAI_LAUNCH_WINO(1, 1, 1);
     else if (stamps && g_wino_timeline_skip == 2) TAI_LAUNCH_WINO(1, 1, 2);

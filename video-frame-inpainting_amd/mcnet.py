@@ -39,7 +39,8 @@ class IndexedConvs(nn.Module):
 
 
 def _conv_relu_chain(x, convs, last_act='relu'):
-    """conv + bias + ReLU for every layer but the last, which gets ``last_act`` ('relu', 'tanh' or None)."""
+    """conv + bias + ReLU for every layer but the last, which gets ``last_act`` ('relu', 'tanh' or None).  ``x`` may be a
+    tuple of tensors standing for their concatenation along the channels (conv_ops.conv_bias_act)."""
     for i, c in enumerate(convs):
         act = 'relu' if i + 1 < len(convs) else last_act
         x = conv_bias_act(x, c.weight, c.bias, c.padding[0], act)
@@ -102,7 +103,7 @@ class CombLayers(nn.Module):
                                     (4, nn.Conv2d(g * 2, g * 4, 3, padding=1))])
 
     def forward(self, h_dyn, h_cont):
-        return _conv_relu_chain(torch.cat((h_dyn, h_cont), dim=1), self.h_comb.convs())
+        return _conv_relu_chain((h_dyn, h_cont), self.h_comb.convs())          # conv(cat(..)) without the cat
 
 
 class Residual(nn.Module):
@@ -113,7 +114,7 @@ class Residual(nn.Module):
         self.res = IndexedConvs([(0, nn.Conv2d(in_dim, out_dim, 3, padding=1)), (2, nn.Conv2d(out_dim, out_dim, 3, padding=1))])
 
     def forward(self, input_dyn, input_cont):
-        return _conv_relu_chain(torch.cat((input_dyn, input_cont), dim=1), self.res.convs(), last_act=None)
+        return _conv_relu_chain((input_dyn, input_cont), self.res.convs(), last_act=None)   # conv(cat(..)) without the cat
 
 
 class DecCnn(nn.Module):

@@ -128,7 +128,7 @@ class TAI(nn.Module):
                 variableRes, ratio=0):
         """variableRes is indexable by 1 and 2 (the merged 1/2- and 1/4-resolution residuals); index 0 is never read."""
         nb = self.num_block
-        x = torch.cat([variableDyn1, variableDyn2, variableCont1, variableCont2], 1)
+        x = (variableDyn1, variableDyn2, variableCont1, variableCont2)      # their concatenation, never materialised
         enc = []
         for i in range(nb - 3):
             conv = _conv_relu_chain(x, self.moduleConv[i].convs())
