@@ -75,6 +75,9 @@ int tai_bias_act_inplace(float* x, const float* bias, int N, int C, int HW, int 
  *                               transpose-and-flip that turns it into a direct convolution). */
 int tai_conv_cin1_forward(const float* x, const float* weight, const float* bias, float* y, int N, int Co, int H, int W,
                           int k, int act, void* hip_stream);
+/* tai_conv_cin1_forward that also writes ypool [N,Co,H/2,W/2] = 2x2 max pool of the activated output (even H). */
+int tai_conv_cin1_forward_maxpool(const float* x, const float* weight, const float* bias, float* y, float* ypool, int N, int Co,
+                                  int H, int W, int k, int act, void* hip_stream);
 int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float* bias, float* y, int N, int Ci, int H,
                                int W, int act, void* hip_stream);
 
@@ -89,6 +92,10 @@ long long tai_conv3x3_wino_weight_floats(int K, int C);
 int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int C, void* hip_stream);
 int tai_conv3x3_wino_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W,
                              int act, void* hip_stream);
+/* The same convolution, also writing ypool [N,K,H/2,W/2] = 2x2 max pool of the activated output (nn.Conv2d + ReLU +
+ * nn.MaxPool2d(2): src/models/mcnet/mcnet.py:84-88, 96-100, 110-114; the un-pooled output is the residual, :118). */
+int tai_conv3x3_wino_forward_maxpool(const float* x, const float* U, const float* bias, float* y, float* ypool, int N, int C,
+                                     int K, int H, int W, int act, void* hip_stream);
 /* The same convolution with the input given as `nparts` (1..4) contiguous [N, C / nparts, H, W] tensors, the operands of
  * a torch.cat along the channels that is then never materialised (Residual: src/models/mcnet/mcnet.py:182, CombLayers
  * :152, TAI.forward: src/models/tai/tai.py:188).  xs: host array of device pointers; C / nparts must be a multiple of 8. */

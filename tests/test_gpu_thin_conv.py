@@ -78,3 +78,18 @@ def test_thin_conv_rejects_bad_arguments():
     assert L.tai_conv_cin1_forward(None, w.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 16, 8, 8, 3, 1, None) != 0
     assert L.tai_conv_cout1_3x3_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 16, 8, 6, 0, None) != 0
     assert b'conv_cout1' in L.tai_sepconv_last_error()
+
+
+@pytest.mark.parametrize('k', [3, 5])
+@pytest.mark.parametrize('shape', [(2, 64, 32, 32), (3, 16, 20, 36)])
+def test_cin1_fused_maxpool(k, shape):
+    from video_frame_inpainting_amd.conv_ops import conv_bias_act, conv_bias_act_maxpool
+    N, Co, H, W = shape
+    g = torch.Generator().manual_seed(k + H)
+    x = torch.randn(N, 1, H, W, generator=g).cuda()
+    w = (torch.randn(Co, 1, k, k, generator=g) * 0.3).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    with torch.no_grad():
+        y, yp = conv_bias_act_maxpool(x, w, b, k // 2, 'relu')
+        assert torch.equal(y, conv_bias_act(x, w, b, k // 2, 'relu'))
+        assert torch.equal(yp, F.max_pool2d(y, 2))

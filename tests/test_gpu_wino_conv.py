@@ -133,3 +133,30 @@ def test_channel_parts_fall_back_to_cat_when_not_eligible():
     from video_frame_inpainting_amd import _native
     L = _native.lib()
     assert L.tai_conv3x3_wino_forward_parts(None, 2, 0, 0, 0, 1, 16, 8, 4, 4, 0, None) != 0
+
+
+@pytest.mark.parametrize('shape', [(16, 64, 64, 64, 64), (3, 24, 51, 12, 20)])
+def test_wino_fused_maxpool(shape):
+    from video_frame_inpainting_amd import _native
+    L = _native.lib()
+    N, C, K, H, W = shape
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, C, H, W, generator=g).cuda(); w = (torch.randn(K, C, 3, 3, generator=g) * 0.1).cuda(); b = torch.randn(K, generator=g).cuda()
+    U = torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), device='cuda')
+    _native.check(L.tai_conv3x3_wino_transform_weights(w.data_ptr(), U.data_ptr(), K, C, None), 'transform')
+    y = torch.full((N, K, H, W), float('nan'), device='cuda'); yp = torch.full((N, K, H // 2, W // 2), float('nan'), device='cuda')
+    _native.check(L.tai_conv3x3_wino_forward_maxpool(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), yp.data_ptr(), N, C, K, H, W, 1, None), 'fwd')
+    assert torch.equal(y, _wino(x, w, b, 'relu'))
+    assert torch.equal(yp, F.max_pool2d(y, 2))
+
+
+def test_encoders_use_the_fused_pool_and_match_aten():
+    from video_frame_inpainting_amd import conv_ops
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1).cuda()
+    x = torch.randn(16, 64, 64, 64, device='cuda')
+    with torch.no_grad():
+        y, yp = conv_ops.conv_bias_act_maxpool(x, conv.weight, conv.bias, 1, 'relu')
+        assert torch.equal(yp, F.max_pool2d(y, 2)) and (y - torch.relu(conv(x))).abs().max().item() <= 5e-5
+        c5 = torch.nn.Conv2d(64, 128, 5, padding=2).cuda()              # MIOpen path: pooled by ATen
+        y, yp = conv_ops.conv_bias_act_maxpool(x, c5.weight, c5.bias, 2, 'relu')
+        assert torch.equal(yp, F.max_pool2d(y, 2)) and (y - torch.relu(c5(x))).abs().max().item() <= 1e-4

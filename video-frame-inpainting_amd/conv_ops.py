@@ -61,6 +61,37 @@ def _wino_ok(N, Ci, Co, H, W, kh, kw, padding):
             and ((N * (H // 2) * (W // 2) + 63) // 64) * ((Co + 63) // 64) >= WINO_MIN_WORKGROUPS)
 
 
+def conv_bias_act_maxpool(x, weight, bias, padding, act):
+    """(y, max_pool2d(y, 2)) with y = conv_bias_act(x, ...): the kernels that own a whole 2x2 window per lane (Winograd,
+    one-input-channel) write the pooled tensor in their epilogue instead of leaving a second pass over y to ATen."""
+    Co, Ci, kh, kw = weight.shape
+    fused = (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and bias is not None and act in (None, 'relu')
+             and x.shape[2] % 2 == 0 and x.shape[3] % 4 == 0
+             and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or bias.requires_grad)))
+    if fused:
+        N, _, H, W = x.shape
+        L = _native.lib()
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        thin_in = Ci == 1 and kh == kw and kh in (3, 5) and padding == kh // 2 and Co >= 16
+        if thin_in or _wino_ok(N, Ci, Co, H, W, kh, kw, padding):
+            x = x.contiguous()
+            y = torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device)
+            yp = torch.empty((N, Co, H // 2, W // 2), dtype=x.dtype, device=x.device)
+            with torch.cuda.device(x.device):
+                if thin_in:
+                    _native.check(L.tai_conv_cin1_forward_maxpool(x.data_ptr(), weight.contiguous().data_ptr(), bias.data_ptr(),
+                                                                  y.data_ptr(), yp.data_ptr(), N, Co, H, W, kh, _ACT[act], stream),
+                                  'tai_conv_cin1_forward_maxpool')
+                else:
+                    U = _wino_weights(weight, False)
+                    _native.check(L.tai_conv3x3_wino_forward_maxpool(x.data_ptr(), U.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                                                     yp.data_ptr(), N, Ci, Co, H, W, _ACT[act], stream),
+                                  'tai_conv3x3_wino_forward_maxpool')
+            return y, yp
+    y = conv_bias_act(x, weight, bias, padding, act)
+    return y, F.max_pool2d(y, 2)
+
+
 def conv_bias_act(x, weight, bias, padding, act, transposed=False):
     """act(conv2d(x, weight, stride 1, padding) + bias), act in {None, 'relu', 'tanh'}.  ``transposed``: ``weight`` is
     the [in, out, 3, 3] weight of a ConvTranspose2d(k 3, stride 1, padding 1), which is the same convolution with the

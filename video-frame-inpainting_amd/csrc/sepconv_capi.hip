@@ -310,6 +310,24 @@ int tai_conv_cin1_forward(const float* x, const float* weight, const float* bias
     return check_launch("conv_cin1");
 }
 
+int tai_conv_cin1_forward_maxpool(const float* x, const float* weight, const float* bias, float* y, float* ypool, int N, int Co,
+                                  int H, int W, int k, int act, void* hip_stream) {
+    g_err[0] = 0;
+    if (!x || !weight || !bias || !y || !ypool) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (N <= 0 || Co <= 0 || H <= 0 || W <= 0 || W % 4 != 0 || H % 2 != 0 || (k != 3 && k != 5) || act < 0 || act > 1)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv_cin1_maxpool: needs W % 4 == 0, even H, k in {3, 5}, act in {0, 1}");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const long long work = (long long)N * (H / 2) * (W / 4);
+    const int blocks = (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192);
+#define TAI_LAUNCH_CIN1P(K, A) hipLaunchKernelGGL((thin::conv_cin1_pool<K, A>), dim3(blocks), dim3(256), 0, s, x, weight, bias, y, ypool, N, Co, H, W)
+    if (k == 3 && act == 0) TAI_LAUNCH_CIN1P(3, 0);
+    else if (k == 3) TAI_LAUNCH_CIN1P(3, 1);
+    else if (act == 0) TAI_LAUNCH_CIN1P(5, 0);
+    else TAI_LAUNCH_CIN1P(5, 1);
+#undef TAI_LAUNCH_CIN1P
+    return check_launch("conv_cin1_maxpool");
+}
+
 int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float* bias, float* y, int N, int Ci, int H,
                                int W, int act, void* hip_stream) {
     g_err[0] = 0;
@@ -343,7 +361,7 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
 }
 
 static int wino_forward_impl(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C,
-                             int K, int H, int W, int act, void* hip_stream, long long* stamps);
+                             int K, int H, int W, int act, void* hip_stream, long long* stamps, float* ypool = nullptr);
 static int g_wino_timeline_skip = 0;   // timeline launches only: loop parts left out (wino_conv.hip.inc, SKIP)
 int tai_conv3x3_wino_timeline_skip(int level) { g_wino_timeline_skip = level; return 0; }
 
@@ -351,6 +369,13 @@ int tai_conv3x3_wino_forward(const float* x, const float* U, const float* bias, 
                              int act, void* hip_stream) {
     const float* xs[4] = {x, x, x, x};
     return wino_forward_impl(xs, 1, U, bias, y, N, C, K, H, W, act, hip_stream, nullptr);
+}
+
+int tai_conv3x3_wino_forward_maxpool(const float* x, const float* U, const float* bias, float* y, float* ypool, int N, int C,
+                                     int K, int H, int W, int act, void* hip_stream) {
+    if (!ypool) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    const float* xs[4] = {x, x, x, x};
+    return wino_forward_impl(xs, 1, U, bias, y, N, C, K, H, W, act, hip_stream, nullptr, ypool);
 }
 
 int tai_conv3x3_wino_forward_parts(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N,
@@ -374,7 +399,7 @@ int tai_conv3x3_wino_forward_timeline(const float* x, const float* U, const floa
 }
 
 static int wino_forward_impl(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C,
-                             int K, int H, int W, int act, void* hip_stream, long long* stamps) {
+                             int K, int H, int W, int act, void* hip_stream, long long* stamps, float* ypool) {
     g_err[0] = 0;
     if (!xs[0] || !U || !bias || !y) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
     const int cpart = C / nparts;
@@ -391,7 +416,7 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
     do {                                                                                                               \
         if (int rc = allow_lds(wino::conv3x3<A, D, ##__VA_ARGS__>, wino::LDS_BYTES)) return rc;                          \
         hipLaunchKernelGGL((wino::conv3x3<A, D, ##__VA_ARGS__>), dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::LDS_BYTES, s,  \
-                           xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, stamps);                              \
+                           xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, Kpad, nchunks, kblocks, stamps);                              \
     } while (0)
     if (stamps && g_wino_timeline_skip == 1) TAI_LAUNCH_WINO(1, 1, 1);
     else if (stamps && g_wino_timeline_skip == 2) TAI_LAUNCH_WINO(1, 1, 2);

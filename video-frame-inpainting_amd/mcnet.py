@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .conv_ops import conv_bias_act
+from .conv_ops import conv_bias_act, conv_bias_act_maxpool
 from .util import gray01
 
 
@@ -47,6 +47,15 @@ def _conv_relu_chain(x, convs, last_act='relu'):
     return x
 
 
+def _conv_relu_chain_pooled(x, convs):
+    """_conv_relu_chain with ReLU on every layer, returning (y, max_pool2d(y, 2)); the pool is fused into the last
+    convolution where the kernel allows it."""
+    for c in convs[:-1]:
+        x = conv_bias_act(x, c.weight, c.bias, c.padding[0], 'relu')
+    c = convs[-1]
+    return conv_bias_act_maxpool(x, c.weight, c.bias, c.padding[0], 'relu')
+
+
 def _convt3x3_as_conv(x, layer, act):
     # ConvTranspose2d(cin, cout, 3, stride 1, padding 1)  ==  conv2d with weight[o, i, ky, kx] = wt[i, o, 2-ky, 2-kx]
     return conv_bias_act(x, layer.weight, layer.bias, 1, act, transposed=True)
@@ -69,10 +78,10 @@ class MotionEnc(nn.Module):
         self.dyn_conv3 = IndexedConvs([(1, nn.Conv2d(gf_dim * 2, gf_dim * 4, 7, padding=3))])
 
     def forward(self, input_diff):
-        c1 = _conv_relu_chain(input_diff, self.dyn_conv1.convs())
-        c2 = _conv_relu_chain(F.max_pool2d(c1, 2), self.dyn_conv2.convs())
-        c3 = _conv_relu_chain(F.max_pool2d(c2, 2), self.dyn_conv3.convs())
-        return F.max_pool2d(c3, 2), [c1, c2, c3]
+        c1, p1 = _conv_relu_chain_pooled(input_diff, self.dyn_conv1.convs())
+        c2, p2 = _conv_relu_chain_pooled(p1, self.dyn_conv2.convs())
+        c3, p3 = _conv_relu_chain_pooled(p2, self.dyn_conv3.convs())
+        return p3, [c1, c2, c3]
 
 
 class ContentEnc(nn.Module):
@@ -87,10 +96,10 @@ class ContentEnc(nn.Module):
                                         (5, nn.Conv2d(g * 4, g * 4, 3, padding=1))])
 
     def forward(self, raw):
-        c1 = _conv_relu_chain(raw, self.cont_conv1.convs())
-        c2 = _conv_relu_chain(F.max_pool2d(c1, 2), self.cont_conv2.convs())
-        c3 = _conv_relu_chain(F.max_pool2d(c2, 2), self.cont_conv3.convs())
-        return F.max_pool2d(c3, 2), [c1, c2, c3]
+        c1, p1 = _conv_relu_chain_pooled(raw, self.cont_conv1.convs())
+        c2, p2 = _conv_relu_chain_pooled(p1, self.cont_conv2.convs())
+        c3, p3 = _conv_relu_chain_pooled(p2, self.cont_conv3.convs())
+        return p3, [c1, c2, c3]
 
 
 class CombLayers(nn.Module):
