@@ -101,10 +101,14 @@ int tai_conv3x3_wino_forward_maxpool(const float* x, const float* U, const float
  * :152, TAI.forward: src/models/tai/tai.py:188).  xs: host array of device pointers; C / nparts must be a multiple of 8. */
 int tai_conv3x3_wino_forward_parts(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N,
                                    int C, int K, int H, int W, int act, void* hip_stream);
-/* Diagnostics: the same launch with ReLU, every workgroup also writes shader-clock stamps to stamps[64 * workgroup + i]:
- * i = 0 entry, 1 prologue done, 2 channel loop done, 3 end, 4 + c end of chunk c (c < 60).  stamps: 64 * workgroups int64. */
+/* Diagnostics (tools/wino_timeline.py): the same launch with ReLU; every workgroup also writes shader-clock stamps to
+ * stamps[64 * workgroup + i]: i = 0 entry, 1 prologue done, 2 channel loop done, 3 end, 4 + c end of chunk c (c < 26),
+ * and after tai_conv3x3_wino_timeline_skip(7) 30 + 16 * c + g end of MFMA group g of chunk c (c < 2).  stamps holds
+ * 64 * workgroups int64.  tai_conv3x3_wino_timeline_skip(level): 0 the full kernel; 1, 2, 5 leave parts of it out to
+ * time what remains (results are then wrong); affects timeline launches only. */
 int tai_conv3x3_wino_forward_timeline(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H,
                                       int W, long long* stamps, void* hip_stream);
+int tai_conv3x3_wino_timeline_skip(int level);
 
 /* Selects a kernel variant for tai_sepconv_forward (benchmarking / tests):
  *   0 = automatic (default), 1 = generic one-thread-per-output kernel (any shape),

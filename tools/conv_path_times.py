@@ -17,7 +17,9 @@ P, _, Fo = (torch.from_numpy(x).to(dev) for x in synthetic.split_clip(clips, 5, 
 calls = collections.OrderedDict()
 orig = conv_ops.conv_bias_act
 def rec(x, weight, bias, padding, act, transposed=False):
-    key = (tuple(x.shape), tuple(weight.shape), padding, act, transposed)
+    parts = len(x) if isinstance(x, (list, tuple)) else 1
+    x0 = x[0] if parts > 1 else x
+    key = ((x0.shape[0], x0.shape[1] * parts, x0.shape[2], x0.shape[3]), tuple(weight.shape), padding, act, transposed, parts)
     calls[key] = calls.get(key, 0) + 1
     return orig(x, weight, bias, padding, act, transposed)
 import video_frame_inpainting_amd.mcnet as mc, video_frame_inpainting_amd.tai as tai
@@ -35,8 +37,10 @@ def t(fn, n=10):
 
 tot = collections.Counter(); alt_gain = 0.0
 print('%d distinct shapes, %d calls per forward' % (len(calls), sum(calls.values())))
-for (xs, ws, pad, act, tr), n in calls.items():
-    x = torch.randn(*xs, device=dev); w = torch.randn(*ws, device=dev) * 0.05
+for (xs, ws, pad, act, tr, parts), n in calls.items():
+    x = torch.randn(*xs, device=dev)
+    if parts > 1: x = tuple(t.contiguous() for t in x.chunk(parts, dim=1))
+    w = torch.randn(*ws, device=dev) * 0.05
     co = ws[1] if tr else ws[0]
     b = torch.zeros(co, device=dev)
     thr = conv_ops.WINO_MIN_WORKGROUPS
@@ -53,5 +57,5 @@ for (xs, ws, pad, act, tr), n in calls.items():
     wgs = ((xs[0] * xs[2] * xs[3] // 4 + 63) // 64) * ((co + 63) // 64)
     tot[path] += ms * n
     if other == other and other < ms: alt_gain += (ms - other) * n
-    print('x%-22s w%-20s k%d %-5s calls=%3d  %-6s %8.3f ms/call   other path %8.3f   wgs %5d  total %7.2f ms' % (xs, ws, ws[2], 'convT' if tr else '', n, path, ms, other, wgs, ms * n), flush=True)
+    print('x%-22s w%-20s k%d %-5s parts=%d calls=%3d  %-6s %8.3f ms/call   other path %8.3f   wgs %5d  total %7.2f ms' % (xs, ws, ws[2], 'convT' if tr else '', parts, n, path, ms, other, wgs, ms * n), flush=True)
 print('per forward:', {k: round(v, 2) for k, v in tot.items()}, ' possible gain by switching paths: %.2f ms' % alt_gain)

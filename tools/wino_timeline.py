@@ -5,10 +5,10 @@ import numpy as np, torch
 from video_frame_inpainting_amd import _native
 L = _native.lib()
 shapes = [(64, 256, 128, 64, 64)] if '--skip' in sys.argv else [(64, 64, 64, 128, 128), (64, 256, 128, 64, 64), (64, 512, 1024, 16, 16), (32, 51, 51, 128, 128)]
-masks = [0] if '--skip' in sys.argv else [0]
+masks = [0, 1, 2, 5] if '--skip' in sys.argv else [0]
 for mask in masks:
     L.tai_conv3x3_wino_timeline_skip(mask)
-    print('skip level', mask, '(1 no transform, 2 + no V writes, 3 + no patch loads, 4 + no weight DMA)')
+    print('skip level', mask, '(0 full kernel; timing-only ablations, results wrong: 1 no patch transform, 2 + no V writes / patch loads, 5 + no output stores)')
     for (N, C, K, H, W) in shapes:
         x = torch.randn(N, C, H, W, device='cuda'); w = torch.randn(K, C, 3, 3, device='cuda') * .05; b = torch.zeros(K, device='cuda')
         U = torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), device='cuda'); y = torch.empty(N, K, H, W, device='cuda')
@@ -20,7 +20,7 @@ for mask in masks:
             _native.check(L.tai_conv3x3_wino_forward_timeline(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), N, C, K, H, W, st.data_ptr(), s), 'fw')
         torch.cuda.synchronize()
         t = st.cpu().numpy().reshape(wgs, 64).astype(np.float64)
-        nch = min((C + 7) // 8, 60)
+        nch = min((C + 7) // 8, 26)
         pro = t[:, 1] - t[:, 0]; loop = t[:, 2] - t[:, 1]; epi = t[:, 3] - t[:, 2]; tot = t[:, 3] - t[:, 0]
         ch = np.diff(np.concatenate([t[:, 1:2], t[:, 4:4 + nch]], axis=1), axis=1)
         print('x(%d,%d,%d,%d)->%d: %d workgroups, %d chunks; clocks: prologue %.0f  loop %.0f (%.0f/chunk; ideal 4096)  epilogue %.0f  total %.0f'

@@ -53,7 +53,7 @@ def _wino_weights(weight, transposed):
     return _cached(weight, ('wino', transposed), make)
 
 
-WINO_MIN_WORKGROUPS = 192      # below this the 64x64-tile kernel leaves most of the 256 CUs idle; MIOpen takes those
+WINO_MIN_WORKGROUPS = 96       # below this the 64x64-tile kernel leaves most of the 256 CUs idle and MIOpen is as fast (measured: tools/conv_path_times.py)
 
 
 def _wino_ok(N, Ci, Co, H, W, kh, kw, padding):

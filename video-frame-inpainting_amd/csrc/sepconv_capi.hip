@@ -420,10 +420,12 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
     } while (0)
     if (stamps && g_wino_timeline_skip == 1) TAI_LAUNCH_WINO(1, 1, 1);
     else if (stamps && g_wino_timeline_skip == 2) TAI_LAUNCH_WINO(1, 1, 2);
-    else if (stamps && g_wino_timeline_skip == 3) TAI_LAUNCH_WINO(1, 1, 3);
+    else if (stamps && g_wino_timeline_skip == 7) TAI_LAUNCH_WINO(1, 2, 0);
     else if (stamps && g_wino_timeline_skip == 5) TAI_LAUNCH_WINO(1, 1, 5);
-    else if (stamps && g_wino_timeline_skip == 6) TAI_LAUNCH_WINO(1, 1, 6);
     else if (stamps) TAI_LAUNCH_WINO(1, 1);
+    else if (nparts > 1 && act == 0) TAI_LAUNCH_WINO(0, 0, 0, 1);
+    else if (nparts > 1 && act == 1) TAI_LAUNCH_WINO(1, 0, 0, 1);
+    else if (nparts > 1) TAI_LAUNCH_WINO(2, 0, 0, 1);
     else if (act == 0) TAI_LAUNCH_WINO(0, 0);
     else if (act == 1) TAI_LAUNCH_WINO(1, 0);
     else TAI_LAUNCH_WINO(2, 0);
