@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Every conv_bias_act call of one bi-TAI forward (TAI_gray, clips/GPU = 32): which kernel takes it (thin / Winograd-MFMA
+"""Every conv_bias_act call of one bi-TAI forward (the layers that end in a fused max pool -- the last convolution of
+every encoder stage -- are not listed, only the 5x5 / 7x7 ones among them, which fall back to conv_bias_act) (TAI_gray, clips/GPU = 32): which kernel takes it (thin / Winograd-MFMA
 / MIOpen), time per call on that path and -- for 3x3 layers -- on the other one, and the total per forward."""
 import collections, sys, os
 import torch
@@ -23,11 +24,11 @@ def rec(x, weight, bias, padding, act, transposed=False):
     calls[key] = calls.get(key, 0) + 1
     return orig(x, weight, bias, padding, act, transposed)
 import video_frame_inpainting_amd.mcnet as mc, video_frame_inpainting_amd.tai as tai
-mc.conv_bias_act = rec; tai.conv_bias_act = rec
+mc.conv_bias_act = rec; tai.conv_bias_act = rec; conv_ops_conv = conv_ops.conv_bias_act; conv_ops.conv_bias_act = rec   # (conv_bias_act_maxpool's fallback goes through it too)
 with torch.no_grad():
     m(5, P, Fo)
 torch.cuda.synchronize()
-mc.conv_bias_act = orig; tai.conv_bias_act = orig
+mc.conv_bias_act = orig; tai.conv_bias_act = orig; conv_ops.conv_bias_act = orig
 
 def t(fn, n=10):
     for _ in range(3): fn()
