@@ -81,6 +81,15 @@ int tai_conv_cin1_forward_maxpool(const float* x, const float* weight, const flo
 int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float* bias, float* y, int N, int Ci, int H,
                                int W, int act, void* hip_stream);
 
+/* k x k (k = 5, 7) "same" convolution as a 3x3 convolution: out [N, S*S*C, H+2, W+4] (S = 2 for k = 5, 3 for k = 7)
+ * receives the S*S shifted copies of x [N, C, H, W], each with its own halo -- out[n][(a*S+b)*C+c][u][v] =
+ * x[n][c][u-1+3a-k/2+1][v-2+3b-k/2+1], zero outside the image -- and the k x k weight, cut into S x S blocks of 3 x 3 taps
+ * ([K, S*S*C, 3, 3], zero past k), is then an ordinary weight for tai_conv3x3_wino_transform_weights; the convolution is
+ * tai_conv3x3_wino_forward_window(out, ..., in_h = H+2, in_w = W+4, in_oy = 1, in_ox = 2).  Replaces
+ * nn.Conv2d(gf, 2gf, 5, padding=2) and nn.Conv2d(2gf, 4gf, 7, padding=3) of MotionEnc (src/models/mcnet/mcnet.py:36-38,
+ * 45-47).  W % 4 == 0. */
+int tai_conv_shift_stack(const float* x, float* out, int N, int C, int H, int W, int k, void* hip_stream);
+
 /* 3x3 stride-1 zero-padded ("same") convolution + bias + activation, fp32 NCHW contiguous, H and W even, computed as
  * Winograd F(2x2,3x3) on the fp32 MFMA pipe.  Replaces nn.Conv2d(C, K, 3, padding=1) [+ ReLU] of the generator and the
  * kernel network (src/models/mcnet/mcnet.py:79-118,131-152,165-170,271; src/models/tai/tai.py:248-286) and, after the
@@ -96,6 +105,11 @@ int tai_conv3x3_wino_forward(const float* x, const float* U, const float* bias, 
  * nn.MaxPool2d(2): src/models/mcnet/mcnet.py:84-88, 96-100, 110-114; the un-pooled output is the residual, :118). */
 int tai_conv3x3_wino_forward_maxpool(const float* x, const float* U, const float* bias, float* y, float* ypool, int N, int C,
                                      int K, int H, int W, int act, void* hip_stream);
+/* The same convolution on an input plane of in_h x in_w that holds output pixel (0, 0) at (in_oy, in_ox) (in_ox and in_w
+ * even): the zero padding applies outside that plane only, so an input that carries its own halo (tai_conv_shift_stack)
+ * is convolved without padding.  ypool may be NULL (no pooled output). */
+int tai_conv3x3_wino_forward_window(const float* x, const float* U, const float* bias, float* y, float* ypool, int N, int C,
+                                    int K, int H, int W, int in_h, int in_w, int in_oy, int in_ox, int act, void* hip_stream);
 /* The same convolution with the input given as `nparts` (1..4) contiguous [N, C / nparts, H, W] tensors, the operands of
  * a torch.cat along the channels that is then never materialised (Residual: src/models/mcnet/mcnet.py:182, CombLayers
  * :152, TAI.forward: src/models/tai/tai.py:188).  xs: host array of device pointers; C / nparts must be a multiple of 8. */

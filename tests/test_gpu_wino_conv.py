@@ -160,3 +160,45 @@ def test_encoders_use_the_fused_pool_and_match_aten():
         c5 = torch.nn.Conv2d(64, 128, 5, padding=2).cuda()              # MIOpen path: pooled by ATen
         y, yp = conv_ops.conv_bias_act_maxpool(x, c5.weight, c5.bias, 2, 'relu')
         assert torch.equal(yp, F.max_pool2d(y, 2)) and (y - torch.relu(c5(x))).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize('k,shape', [(5, (16, 64, 128, 64, 64)), (7, (16, 128, 256, 32, 32)), (5, (48, 16, 24, 20, 28))])
+@pytest.mark.parametrize('pool', [False, True])
+def test_5x5_and_7x7_through_the_winograd_kernel(k, shape, pool):
+    """MotionEnc's 5x5 / 7x7 layers (mcnet.py:36-38, 45-47) as a 3x3 convolution over shifted copies of the input."""
+    from video_frame_inpainting_amd import conv_ops
+    N, C, K, H, W = shape
+    g = torch.Generator().manual_seed(k * 100 + H)
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    conv = torch.nn.Conv2d(C, K, k, padding=k // 2).cuda()
+    with torch.no_grad():
+        if pool:
+            y, yp = conv_ops.conv_bias_act_maxpool(x, conv.weight, conv.bias, k // 2, 'relu')
+            assert torch.equal(yp, F.max_pool2d(y, 2))
+        else:
+            y = conv_ops.conv_bias_act(x, conv.weight, conv.bias, k // 2, 'relu')
+        assert ('wino_kxk', False) in conv.weight._tai_derived                    # not the MIOpen path
+        ref = torch.relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=k // 2))
+        mag = F.conv2d(x.double().abs(), conv.weight.double().abs(), conv.bias.double().abs(), padding=k // 2)
+    err = ((y.double() - ref).abs() / (1 + mag)).max().item()
+    assert err <= 4e-6, err
+
+
+def test_shift_stack_layout():
+    from video_frame_inpainting_amd import _native
+    L = _native.lib()
+    N, C, H, W, k = 2, 3, 6, 8, 5
+    x = torch.arange(N * C * H * W, dtype=torch.float32, device='cuda').view(N, C, H, W) + 1
+    out = torch.full((N, 4 * C, H + 2, W + 4), float('nan'), device='cuda')
+    _native.check(L.tai_conv_shift_stack(x.data_ptr(), out.data_ptr(), N, C, H, W, k, None), 'stack')
+    for a in range(2):
+        for b in range(2):
+            oy, ox = 3 * a - 1, 3 * b - 1
+            blk = out[:, (a * 2 + b) * C:(a * 2 + b + 1) * C]
+            ref = torch.zeros_like(blk)
+            for u in range(H + 2):
+                for v in range(W + 4):
+                    sy, sx = u - 1 + oy, v - 2 + ox
+                    if 0 <= sy < H and 0 <= sx < W:
+                        ref[:, :, u, v] = x[:, :, sy, sx]
+            assert torch.equal(blk, ref)

@@ -74,6 +74,8 @@ def lib():
     L.tai_conv3x3_wino_forward.restype = I
     L.tai_conv3x3_wino_forward_maxpool.argtypes = [P, P, P, P, P, I, I, I, I, I, I, V]
     L.tai_conv3x3_wino_forward_maxpool.restype = I
+    L.tai_conv3x3_wino_forward_window.argtypes = [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, V]
+    L.tai_conv3x3_wino_forward_window.restype = I
     L.tai_conv3x3_wino_forward_parts.argtypes = [P, I, P, P, P, I, I, I, I, I, I, V]
     L.tai_conv3x3_wino_forward_parts.restype = I
     L.tai_conv3x3_wino_forward_timeline.argtypes = [P, P, P, P, I, I, I, I, I, P, V]
@@ -82,6 +84,8 @@ def lib():
     L.tai_conv_cin1_forward.restype = I
     L.tai_conv_cin1_forward_maxpool.argtypes = [P, P, P, P, P, I, I, I, I, I, I, V]
     L.tai_conv_cin1_forward_maxpool.restype = I
+    L.tai_conv_shift_stack.argtypes = [P, P, I, I, I, I, I, V]
+    L.tai_conv_shift_stack.restype = I
     L.tai_conv_cout1_3x3_forward.argtypes = [P, P, P, P, I, I, I, I, I, V]
     L.tai_conv_cout1_3x3_forward.restype = I
     L.tai_bias_act_inplace.argtypes = [P, P, I, I, I, I, V]

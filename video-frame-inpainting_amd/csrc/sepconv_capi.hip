@@ -328,6 +328,18 @@ int tai_conv_cin1_forward_maxpool(const float* x, const float* weight, const flo
     return check_launch("conv_cin1_maxpool");
 }
 
+int tai_conv_shift_stack(const float* x, float* out, int N, int C, int H, int W, int k, void* hip_stream) {
+    g_err[0] = 0;
+    if (!x || !out) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || W % 4 != 0 || (k != 5 && k != 7))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv_shift_stack: needs W % 4 == 0 and k in {5, 7}");
+    const int S = k == 5 ? 2 : 3;
+    const long long work = (long long)N * S * S * C * (H + 2) * ((W + 4) / 4);
+    const int blocks = (int)((work + 255) / 256 < 16384 ? (work + 255) / 256 : 16384);
+    hipLaunchKernelGGL(thin::shift_stack, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), x, out, N, C, H, W, S, k);
+    return check_launch("conv_shift_stack");
+}
+
 int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float* bias, float* y, int N, int Ci, int H,
                                int W, int act, void* hip_stream) {
     g_err[0] = 0;
@@ -361,7 +373,8 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
 }
 
 static int wino_forward_impl(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C,
-                             int K, int H, int W, int act, void* hip_stream, long long* stamps, float* ypool = nullptr);
+                             int K, int H, int W, int act, void* hip_stream, long long* stamps, float* ypool = nullptr,
+                             int in_h = 0, int in_w = 0, int in_oy = 0, int in_ox = 0);
 static int g_wino_timeline_skip = 0;   // timeline launches only: loop parts left out (wino_conv.hip.inc, SKIP)
 int tai_conv3x3_wino_timeline_skip(int level) { g_wino_timeline_skip = level; return 0; }
 
@@ -376,6 +389,12 @@ int tai_conv3x3_wino_forward_maxpool(const float* x, const float* U, const float
     if (!ypool) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
     const float* xs[4] = {x, x, x, x};
     return wino_forward_impl(xs, 1, U, bias, y, N, C, K, H, W, act, hip_stream, nullptr, ypool);
+}
+
+int tai_conv3x3_wino_forward_window(const float* x, const float* U, const float* bias, float* y, float* ypool, int N, int C,
+                                    int K, int H, int W, int in_h, int in_w, int in_oy, int in_ox, int act, void* hip_stream) {
+    const float* xs[4] = {x, x, x, x};
+    return wino_forward_impl(xs, 1, U, bias, y, N, C, K, H, W, act, hip_stream, nullptr, ypool, in_h, in_w, in_oy, in_ox);
 }
 
 int tai_conv3x3_wino_forward_parts(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N,
@@ -399,13 +418,17 @@ int tai_conv3x3_wino_forward_timeline(const float* x, const float* U, const floa
 }
 
 static int wino_forward_impl(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C,
-                             int K, int H, int W, int act, void* hip_stream, long long* stamps, float* ypool) {
+                             int K, int H, int W, int act, void* hip_stream, long long* stamps, float* ypool, int in_h,
+                             int in_w, int in_oy, int in_ox) {
+    if (in_h == 0) { in_h = H; in_w = W; }
     g_err[0] = 0;
     if (!xs[0] || !U || !bias || !y) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
     const int cpart = C / nparts;
     if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2 || act < 0 || act > 2)
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: needs even H and W, act in {0, 1, 2}");
-    if ((long long)N * (C > K ? C : K) * H * W >= (1LL << 29))       // byte offsets stay below 2^31 (buffer addressing)
+    if (in_h < H + in_oy || in_w < W + in_ox || in_oy < 0 || in_ox < 0 || in_ox % 2 || in_w % 2)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: bad input window");
+    if ((long long)N * C * in_h * in_w >= (1LL << 29) || (long long)N * K * H * W >= (1LL << 29))   // byte offsets < 2^31
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: tensor too large (2^29 elements or more)");
     const int Kpad = (K + wino::TM - 1) / wino::TM * wino::TM, Cpad = (C + wino::KC - 1) / wino::KC * wino::KC;
     const int kblocks = Kpad / wino::TM, nchunks = Cpad / wino::KC;
@@ -416,7 +439,7 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
     do {                                                                                                               \
         if (int rc = allow_lds(wino::conv3x3<A, D, ##__VA_ARGS__>, wino::LDS_BYTES)) return rc;                          \
         hipLaunchKernelGGL((wino::conv3x3<A, D, ##__VA_ARGS__>), dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::LDS_BYTES, s,  \
-                           xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, Kpad, nchunks, kblocks, stamps);                              \
+                           xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, Kpad, nchunks, kblocks, stamps);                              \
     } while (0)
     if (stamps && g_wino_timeline_skip == 1) TAI_LAUNCH_WINO(1, 1, 1);
     else if (stamps && g_wino_timeline_skip == 2) TAI_LAUNCH_WINO(1, 1, 2);
