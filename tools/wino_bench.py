@@ -42,3 +42,21 @@ for (N, C, K, H, W) in shapes:
     tm = t(run); ta = t(lambda: torch.relu_(F.conv2d(x, w, b, padding=1)))
     fl = 2.0 * N * K * C * 9 * H * W
     print('x(%d,%d,%d,%d)->%d  wino %.0f us %.0f TF | miopen %.0f us %.0f TF | err vs f64: wino %.2e miopen %.2e' % (N, C, H, W, K, tm, fl / tm / 1e6, ta, fl / ta / 1e6, e_mine, e_aten), flush=True)
+
+# MotionEnc's 5x5 / 7x7 layers: shift-stack + Winograd 3x3 (conv_ops) against MIOpen's direct form
+from video_frame_inpainting_amd import conv_ops
+print('k x k layers through the 3x3 Winograd kernel (shifted copies of the input, csrc/thin_conv.hip.inc shift_stack):')
+for (N, C, K, H, W, k) in [(64, 64, 128, 64, 64, 5), (64, 128, 256, 32, 32, 7)]:
+    g = torch.Generator().manual_seed(k)
+    x = torch.randn(N, C, H, W, generator=g).cuda(); w = (torch.randn(K, C, k, k, generator=g) * (2.0 / (k * k * C)) ** .5).cuda(); b = torch.randn(K, generator=g).cuda()
+    with torch.no_grad():
+        y = conv_ops.conv_bias_act(x, w, b, k // 2, 'relu')
+        ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=k // 2))
+        r32 = torch.relu(F.conv2d(x, w, b, padding=k // 2))
+        tm = t(lambda: conv_ops.conv_bias_act(x, w, b, k // 2, 'relu')); ta = t(lambda: torch.relu_(F.conv2d(x, w, b, padding=k // 2)))
+        S = (k + 2) // 3
+        st = torch.empty(N, S * S * C, H + 2, W + 4, device='cuda')
+        ts = t(lambda: L.tai_conv_shift_stack(x.data_ptr(), st.data_ptr(), N, C, H, W, k, None))
+    fl = 2.0 * N * K * C * k * k * H * W
+    print('x(%d,%d,%d,%d)->%d %dx%d  shift-stack + wino %.0f us (stack alone %.0f) %.0f TF | miopen %.0f us %.0f TF | err vs f64: wino %.2e miopen %.2e'
+          % (N, C, H, W, K, k, k, tm, ts, fl / tm / 1e6, ta, fl / ta / 1e6, (y.double() - ref).abs().max().item(), (r32.double() - ref).abs().max().item()), flush=True)

@@ -5,10 +5,10 @@ import numpy as np, torch
 from video_frame_inpainting_amd import _native
 L = _native.lib()
 shapes = [(64, 256, 128, 64, 64)] if '--skip' in sys.argv else [(64, 64, 64, 128, 128), (64, 256, 128, 64, 64), (64, 512, 1024, 16, 16), (32, 51, 51, 128, 128)]
-masks = [0, 1, 2, 5] if '--skip' in sys.argv else [0]
+masks = [0, 1, 4, 2, 5] if '--skip' in sys.argv else [0]
 for mask in masks:
     L.tai_conv3x3_wino_timeline_skip(mask)
-    print('skip level', mask, '(0 full kernel; timing-only ablations, results wrong: 1 no patch transform, 2 + no V writes / patch loads, 5 + no output stores)')
+    print('skip level', mask, '(0 full kernel; timing-only ablations, results wrong: 1 no patch transform, 4 + no patch loads, 2 + no V writes, 5 + no output stores)')
     for (N, C, K, H, W) in shapes:
         x = torch.randn(N, C, H, W, device='cuda'); w = torch.randn(K, C, 3, 3, device='cuda') * .05; b = torch.zeros(K, device='cuda')
         U = torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), device='cuda'); y = torch.empty(N, K, H, W, device='cuda')

@@ -443,6 +443,7 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
     } while (0)
     if (stamps && g_wino_timeline_skip == 1) TAI_LAUNCH_WINO(1, 1, 1);
     else if (stamps && g_wino_timeline_skip == 2) TAI_LAUNCH_WINO(1, 1, 2);
+    else if (stamps && g_wino_timeline_skip == 4) TAI_LAUNCH_WINO(1, 1, 4);
     else if (stamps && g_wino_timeline_skip == 7) TAI_LAUNCH_WINO(1, 2, 0);
     else if (stamps && g_wino_timeline_skip == 5) TAI_LAUNCH_WINO(1, 1, 5);
     else if (stamps) TAI_LAUNCH_WINO(1, 1);
