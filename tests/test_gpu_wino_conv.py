@@ -202,3 +202,30 @@ def test_shift_stack_layout():
                     if 0 <= sy < H and 0 <= sx < W:
                         ref[:, :, u, v] = x[:, :, sy, sx]
             assert torch.equal(blk, ref)
+
+
+@pytest.mark.parametrize('transposed', [False, True])
+@pytest.mark.parametrize('act', [None, 'relu', 'tanh'])
+def test_training_form_gradients_match_autograd_of_conv2d(act, transposed):
+    """Forward and input gradient on the Winograd kernel, weight / bias gradients from MIOpen, against fp64 autograd."""
+    from video_frame_inpainting_amd import conv_ops
+    g = torch.Generator().manual_seed(17)
+    N, C, K, H, W = 32, 64, 128, 32, 32
+    x = torch.randn(N, C, H, W, generator=g).cuda().requires_grad_(True)
+    wshape = (C, K, 3, 3) if transposed else (K, C, 3, 3)
+    w = (torch.randn(*wshape, generator=g) * 0.05).cuda().requires_grad_(True)
+    b = torch.randn(K, generator=g).cuda().requires_grad_(True)
+    go = torch.randn(N, K, H, W, generator=g).cuda()
+    y = conv_ops.conv_bias_act(x, w, b, 1, act, transposed=transposed)
+    assert type(y.grad_fn).__name__ == '_WinoConv3x3Backward'
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), go)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    weff = wd.transpose(0, 1).flip(2, 3) if transposed else wd
+    yd = F.conv2d(xd, weff, bd, padding=1)
+    yd = torch.relu(yd) if act == 'relu' else (torch.tanh(yd) if act == 'tanh' else yd)
+    rx, rw, rb = torch.autograd.grad(yd, (xd, wd, bd), go.double())
+    # y and gx are 576- / 1152-term fp32 sums; gw and gb sum over all 32,768 pixels (MIOpen, fp32), and a ReLU whose
+    # pre-activation is within rounding of zero may open in one precision and not in the other
+    for got, ref, tol in ((y, yd, 1e-5), (gx, rx, 2e-4), (gw, rw, 2e-4), (gb, rb, 2e-4)):
+        err = (got.double() - ref).abs().max().item() / (1 + ref.abs().max().item())
+        assert err <= tol, err

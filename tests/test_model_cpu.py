@@ -335,3 +335,40 @@ def test_quant_eval_pipeline_on_png_frames(tmp_path):
     assert 'bi-TAI (ours)' in txt and ('%.2f' % want_p.mean(axis=1).mean()) in txt and txt.startswith('+')
     with pytest.raises(RuntimeError):
         compute_quant_results.main([str(tmp_path / 'qual'), str(tmp_path / 'quant'), '5', '5'])
+
+
+def test_kxk_convolution_as_blocked_3x3_over_shifted_haloed_copies():
+    """The formulation behind tai_conv_shift_stack + tai_conv3x3_wino_forward_window (MotionEnc's 5x5 / 7x7 layers,
+    mcnet.py:36-38, 45-47), in plain torch: S*S shifted copies with their own halo, the k x k filter cut into S x S
+    blocks of 3 x 3 taps, one unpadded 3x3 convolution."""
+    import torch.nn.functional as F
+    from video_frame_inpainting_amd.conv_ops import _block3x3_weight
+    for k in (5, 7):
+        g = torch.Generator().manual_seed(k)
+        x = torch.randn(2, 3, 10, 12, generator=g, dtype=torch.float64)
+        w = torch.randn(4, 3, k, k, generator=g, dtype=torch.float64)
+        S = (k + 2) // 3
+        N, C, H, W = x.shape
+        stack = torch.zeros(N, S * S * C, H + 2, W + 4, dtype=torch.float64)
+        for a in range(S):
+            for b in range(S):
+                oy, ox = 3 * a - k // 2 + 1, 3 * b - k // 2 + 1
+                for u in range(H + 2):
+                    for v in range(W + 4):
+                        sy, sx = u - 1 + oy, v - 2 + ox
+                        if 0 <= sy < H and 0 <= sx < W:
+                            stack[:, (a * S + b) * C:(a * S + b + 1) * C, u, v] = x[:, :, sy, sx]
+        y = F.conv2d(stack, _block3x3_weight(w))[:, :, :, 1:W + 1]          # "valid" on the haloed plane, origin (1, 2)
+        ref = F.conv2d(x, w, padding=k // 2)
+        assert (y - ref).abs().max().item() < 1e-12
+
+
+def test_conv_bias_act_takes_channel_parts_on_cpu():
+    from video_frame_inpainting_amd.conv_ops import conv_bias_act, conv_bias_act_maxpool
+    import torch.nn.functional as F
+    a, b = torch.randn(2, 8, 6, 6), torch.randn(2, 8, 6, 6)
+    conv = torch.nn.Conv2d(16, 4, 3, padding=1)
+    with torch.no_grad():
+        assert torch.equal(conv_bias_act((a, b), conv.weight, conv.bias, 1, 'relu'), torch.relu(conv(torch.cat((a, b), 1))))
+        y, yp = conv_bias_act_maxpool(a, torch.nn.Conv2d(8, 4, 3, padding=1).weight, conv.bias, 1, 'relu')
+        assert torch.equal(yp, F.max_pool2d(y, 2))

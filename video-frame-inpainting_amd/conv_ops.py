@@ -112,6 +112,54 @@ def _wino_ok(N, Ci, Co, H, W, kh, kw, padding):
             and ((N * (H // 2) * (W // 2) + 63) // 64) * ((Co + 63) // 64) >= WINO_MIN_WORKGROUPS)
 
 
+def _wino_launch(x, U, bias, N, Ci, Co, H, W, act):
+    y = torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _native.check(_native.lib().tai_conv3x3_wino_forward(x.data_ptr(), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci, Co,
+                                                            H, W, _ACT[act], torch.cuda.current_stream(x.device).cuda_stream),
+                      'tai_conv3x3_wino_forward')
+    return y
+
+
+class _WinoConv3x3(torch.autograd.Function):
+    """Training form of the 3x3 convolution: the forward and the input gradient (the same convolution with the weight
+    transposed and flipped) run on the Winograd-MFMA kernel; the weight and bias gradients are MIOpen's
+    (aten.convolution_backward).  ``transposed``: the weight is a ConvTranspose2d(k 3, stride 1, padding 1) weight."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, transposed):
+        x = x.contiguous()
+        Co, Ci = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
+        N, _, H, W = x.shape
+        y = _wino_launch(x, _wino_weights(weight, transposed), bias, N, Ci, Co, H, W, act)
+        ctx.act, ctx.transposed = act, transposed
+        ctx.save_for_backward(x, weight, y if act is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, y = ctx.saved_tensors
+        g = grad_out.contiguous()
+        if ctx.act == 'relu':
+            g = g * (y > 0).to(g.dtype)
+        elif ctx.act == 'tanh':
+            g = g * (1 - y * y)
+        N, Ci, H, W = x.shape
+        Co = g.shape[1]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            # d/dx of conv(x, w_eff) is conv(g, w_eff transposed and flipped): the other orientation of the same weight
+            zero = torch.zeros(Ci, dtype=g.dtype, device=g.device)
+            gx = _wino_launch(g, _wino_weights(weight, not ctx.transposed), zero, N, Co, Ci, H, W, None)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            w_eff = _as_conv_weight(weight, ctx.transposed)
+            _, gw_eff, gb = torch.ops.aten.convolution_backward(g, x, w_eff, [Co], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                                [False, ctx.needs_input_grad[1], ctx.needs_input_grad[2]])
+            if ctx.needs_input_grad[1]:
+                gw = _as_conv_weight(gw_eff, ctx.transposed)      # the transpose-and-flip is its own inverse
+        return gx, gw, gb, None, None
+
+
 def conv_bias_act_maxpool(x, weight, bias, padding, act):
     """(y, max_pool2d(y, 2)) with y = conv_bias_act(x, ...): the kernels that own a whole 2x2 window per lane (Winograd,
     one-input-channel) write the pooled tensor in their epilogue instead of leaving a second pass over y to ATen."""
@@ -174,6 +222,11 @@ def conv_bias_act(x, weight, bias, padding, act, transposed=False):
     fused = (x.is_cuda and x.dtype == torch.float32 and bias is not None
              and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or bias.requires_grad)))
     if not fused:
+        if x.is_cuda and x.dtype == torch.float32 and bias is not None and weight.shape[2] == weight.shape[3] == 3:
+            Co, Ci = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
+            N, _, H, W = x.shape
+            if _wino_ok(N, Ci, Co, H, W, 3, 3, padding) and _wino_ok(N, Co, Ci, H, W, 3, 3, padding):
+                return _WinoConv3x3.apply(x, weight, bias, act, transposed)      # training: autograd through the HIP kernel
         y = F.conv2d(x, _as_conv_weight(weight, transposed), bias, stride=1, padding=padding)
         return torch.relu(y) if act == 'relu' else (torch.tanh(y) if act == 'tanh' else y)
     kh, kw = weight.shape[2], weight.shape[3]
