@@ -1,0 +1,99 @@
+"""Clip I/O (video_frame_inpainting_amd/data.py) against the reference's dataset semantics (src/data/base_dataset.py):
+list formats, clip labels, the per-frame pipeline, and predict.py on a list of frame directories."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+import video_frame_inpainting_amd as vfi
+from video_frame_inpainting_amd import data as vdata
+from video_frame_inpainting_amd.util import bgr2gray
+
+
+def _frames(T=12, H=24, W=32, seed=0):
+    rng = np.random.RandomState(seed)
+    base = rng.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    return np.stack([np.roll(base, t, axis=1) for t in range(T)])            # [T, H, W, 3] RGB, moving pattern
+
+
+def _png_dir(root, name, frames):
+    d = os.path.join(root, name)
+    os.makedirs(d)
+    for t, f in enumerate(frames):
+        Image.fromarray(f).save(os.path.join(d, 'frame_%04d.png' % t))
+    return d
+
+
+def test_contiguous_list_labels_and_pipeline(tmp_path):
+    fr = _frames()
+    d = _png_dir(str(tmp_path), 'person01_walking', fr)
+    lst = tmp_path / 'list.txt'
+    lst.write_text('%s 3-9\n%s\n' % (d, d))
+    ds = vdata.ContiguousVideoClipDataset(3, str(lst), 7, False, False, (24, 32), False, (8, 0))
+    assert len(ds) == 2
+    it = ds[0]
+    assert it['clip_label'] == 'person01_walking_3-9'                         # basename_a-b, 1-indexed inclusive (:188)
+    x = it['targets']
+    assert x.shape == (7, 3, 24 + 8, 32) and x.dtype == torch.float32
+    # the only 7-frame window of frames 3..9 (1-indexed) is frames 2..8 (0-indexed); BGR order; [-1, 1]; bottom pad = -1
+    want = torch.from_numpy(fr[2:9, :, :, ::-1].copy()).permute(0, 3, 1, 2).float() / 255 * 2 - 1
+    assert torch.allclose(x[:, :, :24], want, atol=1e-6)
+    assert torch.all(x[:, :, 24:] == -1.0)
+    assert ds[1]['clip_label'] == 'person01_walking_1-12'                     # whole video when no range is given
+
+
+def test_gray_and_npy_source_and_disjoint_list(tmp_path):
+    fr = _frames(T=15)
+    np.save(tmp_path / 'clip.npy', fr)
+    lst = tmp_path / 'd.txt'
+    lst.write_text('%s 1-5 11-15\n' % (tmp_path / 'clip.npy'))
+    ds = vdata.DisjointVideoClipDataset(1, str(lst), 5, 5, (24, 32), (0, 0))
+    it = ds[0]
+    assert it['clip_label'] == 'clip.npy_1-5_11-15'                           # (:241)
+    x = it['targets']
+    assert x.shape == (10, 1, 24, 32)
+    idx = list(range(0, 5)) + list(range(10, 15))
+    bgr = torch.from_numpy(fr[idx][:, :, :, ::-1].copy()).permute(0, 3, 1, 2).float() / 255 * 2 - 1
+    assert torch.allclose(x, bgr2gray(bgr), atol=1e-6)
+    lst.write_text('%s 1-5\n' % (tmp_path / 'clip.npy'))
+    with pytest.raises(RuntimeError, match='format'):                         # (:219-222)
+        vdata.DisjointVideoClipDataset(1, str(lst), 5, 5, (24, 32), (0, 0))[0]
+
+
+def test_error_behaviour(tmp_path):
+    lst = tmp_path / 'l.txt'
+    lst.write_text('%s 1-4\n' % (tmp_path / 'missing'))
+    ds = vdata.ContiguousVideoClipDataset(3, str(lst), 4, False, False, (8, 8), False, (0, 0))
+    with pytest.warns(UserWarning), pytest.raises(RuntimeError, match='could not be opened'):       # (:163-166)
+        ds[0]
+    d = _png_dir(str(tmp_path), 'short', _frames(T=3, H=8, W=8))
+    lst.write_text('%s 1-3\n' % d)
+    with pytest.raises(RuntimeError, match='too short'):                                               # (:176-180)
+        vdata.ContiguousVideoClipDataset(3, str(lst), 4, False, False, (8, 8), False, (0, 0))[0]
+
+
+def test_resize_is_opencv_style_bilinear():
+    f = np.zeros((2, 2, 3), np.uint8)
+    f[0, 0], f[0, 1], f[1, 0], f[1, 1] = 0, 100, 200, 40
+    out = vdata.resize_bilinear(f, 4, 4)
+    # half-pixel centres: output x = 0, 1, 2, 3 sample source -0.25, 0.25, 0.75, 1.25 (edge-clamped)
+    row0 = [0, 25, 75, 100]
+    assert out[0, :, 0].tolist() == row0
+    assert out[1, 0, 0] == 50 and out[3, 3, 0] == 40
+    assert vdata.resize_bilinear(f, 2, 2) is f
+    big = _frames(T=1, H=48, W=64)[0]
+    assert vdata.resize_bilinear(big, 24, 32).shape == (24, 32, 3)
+
+
+def test_flip_and_backwards_augmentation(tmp_path, monkeypatch):
+    fr = _frames(T=6, H=8, W=8)
+    np.save(tmp_path / 'c.npy', fr)
+    lst = tmp_path / 'l.txt'
+    lst.write_text('%s 1-6\n' % (tmp_path / 'c.npy'))
+    ds = vdata.ContiguousVideoClipDataset(3, str(lst), 6, True, True, (8, 8), False, (0, 0))
+    monkeypatch.setattr(vdata.random, 'random', lambda: 0.9)                  # both augmentations on (:66-67)
+    x = ds[0]['targets']
+    want = torch.from_numpy(fr[::-1, :, ::-1, ::-1].copy()).permute(0, 3, 1, 2).float() / 255 * 2 - 1
+    assert torch.allclose(x, want, atol=1e-6)

@@ -205,3 +205,39 @@ def test_predict_and_train_drivers_run_end_to_end(tmp_path, monkeypatch):
     from PIL import Image
     im = np.asarray(Image.open(tmp_path / 'res' / 'synthetic_000002' / 'pred_middle_0003.png'))
     assert im.shape == (32, 32) and im.dtype == np.uint8
+
+
+def test_predict_on_reference_style_video_lists(tmp_path, monkeypatch):
+    """predict.py on the reference's list files (contiguous and --disjoint_clips), videos = directories of PNG frames."""
+    import predict
+    from PIL import Image
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.RandomState(3)
+    for name in ('vidA', 'vidB'):
+        os.makedirs(tmp_path / name)
+        base = rng.randint(0, 256, (40, 48, 3)).astype(np.uint8)
+        for t in range(10):
+            Image.fromarray(np.roll(base, 2 * t, axis=1)).save(tmp_path / name / ('%03d.png' % t))
+    (tmp_path / 'contig.txt').write_text('%s 1-8\n%s 2-9\n' % (tmp_path / 'vidA', tmp_path / 'vidB'))
+    (tmp_path / 'disjoint.txt').write_text('%s 1-3 6-8\n' % (tmp_path / 'vidA'))
+    spec = '{"class": "TAIFillInModel", "args": [4, 1, 3, 51], "kwargs": {"num_block": 5, "kf_dim": 2}}'
+    common = ['--name', 'lst', '--K', '3', '--T', '2', '--F', '3', '--c_dim', '1', '--image_size', '32', '--model_key', spec,
+              '--checkpoints_dir', str(tmp_path / 'ckpt'), '--batch_size', '2', '--random_init']
+    predict.main(common + ['--test_video_list_path', str(tmp_path / 'contig.txt'), '--qual_result_root', str(tmp_path / 'r1')])
+    assert sorted(os.listdir(tmp_path / 'r1')) == ['vidA_1-8', 'vidB_2-9']
+    files = sorted(os.listdir(tmp_path / 'r1' / 'vidB_2-9'))
+    assert files == sorted(['gt_preceding_%04d.png' % i for i in range(3)] + ['gt_middle_%04d.png' % i for i in (3, 4)] +
+                           ['gt_following_%04d.png' % i for i in (5, 6, 7)] + ['pred_middle_%04d.png' % i for i in (3, 4)])
+    # the ground-truth PNG is the resized gray frame: frame 2 (1-indexed) of vidB resized 40x48 -> 32x32
+    from video_frame_inpainting_amd import data as vdata
+    src = np.asarray(Image.open(tmp_path / 'vidB' / '001.png'))
+    bgr = vdata.resize_bilinear(src, 32, 32)[:, :, ::-1].astype(np.float32) / 255 * 2 - 1
+    gray = 0.1140 * bgr[:, :, 0] + 0.5870 * bgr[:, :, 1] + 0.2989 * bgr[:, :, 2]
+    want = (255 * (np.clip(gray, -1, 1) + 1) / 2).astype(np.uint8)
+    got = np.asarray(Image.open(tmp_path / 'r1' / 'vidB_2-9' / 'gt_preceding_0000.png'))
+    assert got.shape == (32, 32) and np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    predict.main(common + ['--test_video_list_path', str(tmp_path / 'disjoint.txt'), '--disjoint_clips',
+                           '--qual_result_root', str(tmp_path / 'r2')])
+    files = sorted(os.listdir(tmp_path / 'r2' / 'vidA_1-3_6-8'))
+    assert files == sorted(['gt_preceding_%04d.png' % i for i in range(3)] + ['gt_following_%04d.png' % i for i in (5, 6, 7)] +
+                           ['pred_middle_%04d.png' % i for i in (3, 4)])       # no gt_middle for disjoint clips
