@@ -241,3 +241,23 @@ def test_predict_on_reference_style_video_lists(tmp_path, monkeypatch):
     files = sorted(os.listdir(tmp_path / 'r2' / 'vidA_1-3_6-8'))
     assert files == sorted(['gt_preceding_%04d.png' % i for i in range(3)] + ['gt_following_%04d.png' % i for i in (5, 6, 7)] +
                            ['pred_middle_%04d.png' % i for i in (3, 4)])       # no gt_middle for disjoint clips
+
+
+def test_train_driver_on_a_video_list(tmp_path, monkeypatch):
+    import train
+    from PIL import Image
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.RandomState(5)
+    lines = []
+    for name in ('v0', 'v1', 'v2'):
+        os.makedirs(tmp_path / name)
+        base = rng.randint(0, 256, (32, 32, 3)).astype(np.uint8)
+        for t in range(12):
+            Image.fromarray(np.roll(base, t, axis=0)).save(tmp_path / name / ('%03d.png' % t))
+        lines.append('%s 1-12' % (tmp_path / name))
+    (tmp_path / 'train.txt').write_text('\n'.join(lines) + '\n')
+    spec = '{"class": "TAIFillInModel", "args": [4, 1, 3, 51], "kwargs": {"num_block": 5, "kf_dim": 2}}'
+    train.main(['--name', 'lst', '--K', '3', '--T', '2', '--F', '3', '--c_dim', '1', '--image_size', '32', '--model_key', spec,
+                '--checkpoints_dir', str(tmp_path / 'ckpt'), '--batch_size', '2', '--max_iter', '2', '--print_freq', '1',
+                '--df_dim', '8', '--train_video_list_path', str(tmp_path / 'train.txt'), '--num_threads', '0'])
+    assert (tmp_path / 'ckpt' / 'lst' / 'model_latest.ckpt').exists()

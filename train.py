@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Training driver for the bi-TAI path: the step sequence of the reference's ``train.py:102-119`` (sample K,T,F ->
-slice the clip -> set_train_inputs -> train() -> forward_train() -> optimize_parameters()) on seeded synthetic clips,
-one process per GPU (data parallel over RCCL when launched with torch.distributed.run), with the reference's snapshot
-files ``model_latest.ckpt`` / ``model_%08d.ckpt`` (train.py:137-140).  TensorBoard logging, the video-list datasets and
-the periodic validation of the reference are dataset plumbing outside the hot path.
+slice the clip -> set_train_inputs -> train() -> forward_train() -> optimize_parameters()), one process per GPU (data
+parallel over RCCL when launched with torch.distributed.run), with the reference's snapshot files ``model_latest.ckpt``
+/ ``model_%08d.ckpt`` (train.py:137-140).  Clips come from ``--train_video_list_path`` (the reference's list format and
+augmentation flags, train.py:37-43; video_frame_inpainting_amd/data.py; each rank shuffles with its own seed) or, with
+``--synthetic N``, from N seeded synthetic clips.  TensorBoard logging and the periodic validation of the reference are
+outside the hot path.
 
   python train.py --name demo --K 5 --T 5 --F 5 --c_dim 1 --image_size 128 --batch_size 4 --model_key TAI_gray \
       --max_iter 10 --synthetic 64
@@ -15,6 +17,7 @@ import torch
 
 import video_frame_inpainting_amd as vfi
 from video_frame_inpainting_amd import parallel, synthetic
+from video_frame_inpainting_amd.data import ContiguousVideoClipDataset
 from video_frame_inpainting_amd.environments import create_training_environment
 from video_frame_inpainting_amd.options import TrainOptions
 
@@ -24,9 +27,24 @@ def main(args=None):
     rank, world, local_rank = parallel.init_from_env()
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
-    n_clips = opt.synthetic or 64
     H, W = opt.image_size[0] + opt.padding_size[0], opt.image_size[1] + opt.padding_size[1]
-    clips = torch.from_numpy(synthetic.make_clips(n_clips, opt.K + opt.T + opt.F, opt.c_dim, H, W, opt.seed + rank))
+    loader = None
+    if getattr(opt, 'train_video_list_path', None) and not opt.synthetic:
+        dataset = ContiguousVideoClipDataset(opt.c_dim, opt.train_video_list_path, opt.K + opt.T + opt.F, not opt.no_backwards,
+                                             not opt.no_flip, opt.image_size, True, opt.padding_size)
+        gen = torch.Generator().manual_seed(opt.seed + 7 * rank)
+        loader = torch.utils.data.DataLoader(dataset, batch_size=opt.batch_size, shuffle=not opt.serial_batches,
+                                             num_workers=opt.num_threads, drop_last=True, generator=gen)
+        print('# training videos = %d' % len(dataset))
+
+        def batches():                                               # inf_data_loader (train.py:41)
+            while True:
+                for item in loader:
+                    yield item['targets']
+        stream = batches()
+    else:
+        n_clips = opt.synthetic or 64
+        clips = torch.from_numpy(synthetic.make_clips(n_clips, opt.K + opt.T + opt.F, opt.c_dim, H, W, opt.seed + rank))
 
     torch.manual_seed(0)
     np.random.seed(0)          # identical (K, T, F) draws on every rank
@@ -42,8 +60,7 @@ def main(args=None):
         total_updates += 1
         env.total_updates = total_updates
         K, T, F = env.sample_KTF(opt.sample_KTF)
-        idx = order.randint(0, n_clips, opt.batch_size)
-        all_frames = clips[idx]
+        all_frames = next(stream) if loader is not None else clips[order.randint(0, n_clips, opt.batch_size)]
         env.set_train_inputs(all_frames[:, :K], all_frames[:, K + T:K + T + F], all_frames[:, K:K + T])
         env.K, env.T, env.F = K, T, F
         env.train()
