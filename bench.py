@@ -15,6 +15,10 @@ The JSON line also carries
                 (6,876,944 B per sample) / mean launch duration from HIP events on the launch stream,
                 against the 8 TB/s HBM3E peak; `traffic` is the PMC-measured HBM bytes per launch from the committed
                 rocprofv3 summary (profiles/), or null;
+  roofline_conv the Winograd F(2x2,3x3) fp32-MFMA convolution kernel -- 88 % of the step's GPU time since it replaced
+                MIOpen -- over the 3x3 layer shapes of this workload, weighted by their call counts: the multiply-adds
+                the algorithm needs on the matrix pipe (16 positions x tiles x K x C = direct-convolution flops / 2.25)
+                / summed launch durations from HIP events, against the 157.3 TFLOP/s dense fp32 MFMA peak;
   cpu_baseline  the CPU oracle (oracle/: PyTorch-CPU convs + the C restatement of the sepconv loops) timed on this
                 host's cores on a bounded sample of the same workload (rank 0, N = 1 only) -- a reported baseline, and
                 the parity check of the GPU output against it.
@@ -99,6 +103,58 @@ def sepconv_roofline(device, B, iters=200, warmup=20):
             'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'kernel': 'sepconv_forward',
             'shape': [B, C_, H_, W_], 'us_per_launch': round(us, 2), 'us_per_launch_first_pass': round(us_first, 2),
             'algorithmic_bytes': nbytes}
+
+
+# (N, C, K, H, W, calls per forward) of the 3x3 convolutions of configs[1] (TAI_gray, 32 clips: both directions batched to
+# 64, the five kernel-network evaluations batched to 160), profiles/r01_conv_path_times.txt; the 5x5 / 7x7 layers appear
+# in the form the kernel sees them (4 / 9 shifted copies stacked on the channels).
+CONV_LAYERS = ((64, 64, 64, 128, 128, 15), (64, 128, 64, 128, 128, 5), (64, 64, 128, 64, 64, 5), (64, 128, 128, 64, 64, 15),
+               (64, 256, 128, 64, 64, 13), (64, 128, 256, 32, 32, 5), (64, 256, 256, 32, 32, 25), (64, 512, 256, 32, 32, 5),
+               (64, 1152, 256, 32, 32, 8), (64, 512, 1024, 16, 16, 8), (64, 512, 256, 16, 16, 5), (160, 51, 51, 128, 128, 4),
+               (160, 64, 64, 64, 64, 9), (160, 64, 51, 64, 64, 4), (160, 256, 64, 64, 64, 1), (160, 512, 128, 32, 32, 1),
+               (160, 1024, 256, 16, 16, 1), (160, 256, 256, 16, 16, 3))
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA
+
+
+def conv_roofline(device):
+    L = _native.lib()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    mfma_flops = direct_flops = seconds = 0.0
+    per_graph = 8
+    with torch.no_grad():
+        for (N, C, K, H, W, calls) in CONV_LAYERS:
+            g = torch.Generator().manual_seed(N + C + K)
+            x = torch.randn(N, C, H, W, generator=g).to(device)
+            w = (torch.randn(K, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).to(device)
+            b = torch.zeros(K, device=device)
+            y = torch.empty(N, K, H, W, device=device)
+            U = torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), device=device)
+            _native.check(L.tai_conv3x3_wino_transform_weights(w.data_ptr(), U.data_ptr(), K, C, stream), 'transform_weights')
+            def launch():
+                _native.check(L.tai_conv3x3_wino_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), N, C, K, H, W, 1,
+                                                         torch.cuda.current_stream(device).cuda_stream), 'wino_forward')
+            launch(); launch()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(per_graph):
+                    launch()
+            graph.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            graph.replay(); graph.replay()
+            e1.record(); e1.synchronize()
+            t = e0.elapsed_time(e1) * 1e-3 / (2 * per_graph)
+            seconds += t * calls
+            direct_flops += 18.0 * N * K * C * H * W * calls
+            mfma_flops += 8.0 * N * K * C * H * W * calls
+            del x, w, y, U, graph
+    achieved = mfma_flops / seconds / 1e12
+    return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': 'wino::conv3x3 (F(2x2,3x3), fp32 MFMA)',
+            'layers': len(CONV_LAYERS), 'launches_per_step': sum(l[5] for l in CONV_LAYERS), 'ms_per_step_in_kernel': round(seconds * 1e3, 2),
+            'direct_conv_tflops': round(direct_flops / seconds / 1e12, 1),
+            'note': 'achieved = Winograd-domain multiply-adds (direct-convolution flops / 2.25, unpadded K and C) per second'}
 
 
 def host_cpu_share(cap=16):
@@ -237,6 +293,9 @@ def main():
     if rank == 0:
         line['roofline'] = sepconv_roofline(device, B)
         log('roofline measured')
+        if B == 32:
+            line['roofline_conv'] = conv_roofline(device)
+            log('convolution roofline measured')
         if world == 1 and not args.no_cpu_baseline:
             base, parity = cpu_baseline_and_parity(model, device)
             line['cpu_baseline'] = base
