@@ -66,6 +66,10 @@ int tai_upsample_bilinear2x_forward(const float* input, float* output, int plane
  * pairs, src/models/mcnet/mcnet.py:28-43,79-102,137-144,172-176,203-225; src/models/tai/tai.py:256-261). */
 int tai_bias_act_inplace(float* x, const float* bias, int N, int C, int HW, int act, void* hip_stream);
 
+/* out [planes, 2h, 2w] = res + fixed_unpooling(x), x [planes, h, w] landing on the even (2i, 2j) sites (DecCnn:
+ * src/models/mcnet/mcnet.py:234-236, 240-256); fp32 contiguous, w even; out may not alias x or res. */
+int tai_unpool2x_add(const float* x, const float* res, float* out, long long planes, int h, int w, void* hip_stream);
+
 /* Direct "same"-padded stride-1 convolutions for the generator's thin layers, bias and activation fused (act: 0 none,
  * 1 ReLU, 2 tanh), fp32 NCHW contiguous, W % 4 == 0:
  *   tai_conv_cin1_forward       x [N,1,H,W], weight [Co,1,k,k] (k in {3,5}), y [N,Co,H,W]   (nn.Conv2d(1, gf, 5, padding=2)

@@ -48,3 +48,20 @@ def test_conv_bias_act_matches_torch(act, shape):
     xg = x.clone().requires_grad_()
     conv_bias_act(xg, w, b, 1, act).sum().backward()
     assert xg.grad is not None
+
+
+def test_unpool2x_add_matches_the_strided_add():
+    from video_frame_inpainting_amd.mcnet import unpool2x_add
+    g = torch.Generator().manual_seed(2)
+    for shape in ((3, 5, 6, 8), (2, 64, 16, 16), (1, 1, 1, 2)):
+        x = torch.randn(*shape, generator=g).cuda()
+        res = torch.randn(shape[0], shape[1], 2 * shape[2], 2 * shape[3], generator=g).cuda()
+        with torch.no_grad():
+            got = unpool2x_add(x, res)
+        want = res.clone()
+        want[:, :, 0::2, 0::2] += x
+        assert torch.equal(got, want)
+    xr = torch.randn(1, 2, 4, 4, device='cuda', requires_grad=True)            # autograd keeps the PyTorch form
+    out = unpool2x_add(xr, torch.zeros(1, 2, 8, 8, device='cuda'))
+    out.sum().backward()
+    assert torch.equal(xr.grad, torch.ones_like(xr))

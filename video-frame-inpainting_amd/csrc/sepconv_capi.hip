@@ -328,6 +328,16 @@ int tai_conv_cin1_forward_maxpool(const float* x, const float* weight, const flo
     return check_launch("conv_cin1_maxpool");
 }
 
+int tai_unpool2x_add(const float* x, const float* res, float* out, long long planes, int h, int w, void* hip_stream) {
+    g_err[0] = 0;
+    if (!x || !res || !out) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (planes <= 0 || h <= 0 || w <= 0 || w % 2 != 0) return fail(TAI_SEPCONV_EINVAL, "%s", "unpool2x_add: needs even w");
+    const long long work = planes * 2 * h * (2 * w / 4);
+    const int blocks = (int)((work + 255) / 256 < 16384 ? (work + 255) / 256 : 16384);
+    hipLaunchKernelGGL(bact::unpool2x_add, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), x, res, out, planes, h, w);
+    return check_launch("unpool2x_add");
+}
+
 int tai_conv_shift_stack(const float* x, float* out, int N, int C, int H, int W, int k, void* hip_stream) {
     g_err[0] = 0;
     if (!x || !out) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");

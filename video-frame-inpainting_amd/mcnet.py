@@ -63,6 +63,16 @@ def _convt3x3_as_conv(x, layer, act):
 
 def unpool2x_add(x, res):
     """fixed_unpooling(x) + res  (mcnet.py:234-236, 240-256): x lands on the even (2i, 2j) sites."""
+    if (x.is_cuda and x.dtype == torch.float32 and res.dtype == torch.float32 and x.shape[3] % 2 == 0
+            and not (torch.is_grad_enabled() and (x.requires_grad or res.requires_grad))):
+        from . import _native
+        x, res = x.contiguous(), res.contiguous()
+        out = torch.empty_like(res)
+        with torch.cuda.device(x.device):
+            _native.check(_native.lib().tai_unpool2x_add(x.data_ptr(), res.data_ptr(), out.data_ptr(), x.shape[0] * x.shape[1],
+                                                         x.shape[2], x.shape[3], torch.cuda.current_stream(x.device).cuda_stream),
+                          'tai_unpool2x_add')
+        return out
     out = res.clone()
     out[:, :, 0::2, 0::2] += x
     return out
