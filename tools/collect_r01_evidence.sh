@@ -11,5 +11,6 @@ echo "[5] conv paths"; timeout -k 10 400 python tools/conv_path_times.py > $out/
 echo "[6] torch profile"; timeout -k 10 300 python tools/torch_profile.py 40 2>/dev/null | grep -v Warn > $out/forward_kernel_table.txt; head -4 $out/forward_kernel_table.txt
 echo "[7] microbench"; (./build/mfma_microbench; ./build/mfma_shadow) > $out/mfma_microbench.txt 2>&1; tail -2 $out/mfma_microbench.txt
 echo "[8] secondary configs"; timeout -k 10 500 python tools/bench_configs.py 2>/dev/null | grep "^{" > $out/secondary_configs.txt; cat $out/secondary_configs.txt | cut -c1-200
+echo "[8b] training step"; timeout -k 10 500 python tools/train_step_bench.py 2>&1 | grep "train\]" > $out/train_step.txt; cat $out/train_step.txt
 echo "[9] rocprof bench"; timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/rocprof_bench.log 2>&1; ls $out/rocprof_bench/*/ | head -5
 echo done
