@@ -21,3 +21,5 @@ for mode in (7,):
     start = t[:, 1] if ch == 0 else t[:, 4]
     d = np.diff(np.concatenate([start[:, None], g], axis=1), axis=1)
     print('chunk', ch, 'per-group median clocks:', ' '.join('%.0f' % v for v in np.median(d, axis=0)))
+
+print('chunk 0 group 0: prologue barrier -> first MFMA issued %.0f clocks' % np.median(t[:, 62] - t[:, 1]))
