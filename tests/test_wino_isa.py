@@ -1,0 +1,54 @@
+"""The Winograd kernel's weight DMA (global_load_lds_dwordx4 in inline asm) is invisible to the compiler's wait counting;
+its completion is awaited by COUNTED s_waitcnt vmcnt(N) that assume N compiler-tracked loads are issued after the last
+DMA of a chunk.  That is a property of the generated code, so it is checked on the generated code: compile the device
+side to assembly and count (csrc/wino_conv.hip.inc; profiles/r01_notes.md item 9)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def device_asm(tmp_path_factory):
+    if shutil.which('hipcc') is None:
+        pytest.skip('hipcc not available')
+    out = tmp_path_factory.mktemp('isa') / 'capi.s'
+    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-w', '-I' + os.path.join(ROOT, 'include'),
+           '--cuda-device-only', '-S', os.path.join(ROOT, 'video-frame-inpainting_amd', 'csrc', 'sepconv_capi.hip'), '-o', str(out)]
+    subprocess.run(cmd, check=True, timeout=900)
+    return open(out).read()
+
+
+def _kernel_bodies(asm, mangled_prefix):
+    names = sorted(set(re.findall(r'^(%s\w*):' % re.escape(mangled_prefix), asm, flags=re.M)))
+    for name in names:
+        i = asm.find(name + ':')
+        yield name, asm[i:asm.find('.end_amdhsa_kernel', i)].splitlines()
+
+
+@pytest.mark.parametrize('parts', [0, 1])
+def test_counted_waits_match_the_loads_behind_the_last_dma(device_asm, parts):
+    # conv3x3<ACT 1, DBG 0, SKIP 0, PARTS parts>: the instantiations the product launches
+    prefix = '_ZN4wino7conv3x3ILi1ELi0ELi0ELi%dE' % parts
+    found = 0
+    for name, lines in _kernel_bodies(device_asm, prefix):
+        found += 1
+        bars = [n for n, l in enumerate(lines) if 's_barrier' in l]
+        segs = [lines[a + 1:b + 1] for a, b in zip([-1] + bars[:-1], bars)]
+        dma_segs = [s for s in segs if any('global_load_lds_dwordx4' in l for l in s)]
+        assert len(dma_segs) == 4, (name, len(dma_segs))         # prologue, the two loop bodies, the odd trailing chunk
+        waits = [[int(m.group(1)) for l in s for m in [re.search(r's_waitcnt vmcnt\((\d+)\)', l)] if m][-1] for s in dma_segs]
+        assert waits[0] == 0, 'prologue must wait for everything issued'
+        for s, w in zip(dma_segs[1:3], waits[1:3]):
+            last = max(n for n, l in enumerate(s) if 'global_load_lds_dwordx4' in l)
+            behind = sum(1 for l in s[last:] if re.search(r'\bbuffer_load_dword', l))
+            assert sum(1 for l in s if 'global_load_lds_dwordx4' in l) == 8
+            assert behind == w == 12, (name, behind, w)
+        # no register spills in the channel loop (they would sit on the MFMA critical path)
+        for s in dma_segs[1:3]:
+            assert not any(re.search(r'\bscratch_(load|store)', l) for l in s), name
+    assert found == 1
