@@ -119,6 +119,9 @@ int tai_conv3x3_wino_forward_window(const float* x, const float* U, const float*
  * :152, TAI.forward: src/models/tai/tai.py:188).  xs: host array of device pointers; C / nparts must be a multiple of 8. */
 int tai_conv3x3_wino_forward_parts(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N,
                                    int C, int K, int H, int W, int act, void* hip_stream);
+/* Benchmarking: 0 keeps every layer on the 64-channel x 64-tile workgroup shape; 1 (default) lets layers whose K is a
+ * multiple of 128 use the 128 x 32 shape.  Returns the previous value. */
+int tai_conv3x3_wino_set_tall(int on);
 /* Diagnostics (tools/wino_timeline.py): the same launch with ReLU; every workgroup also writes shader-clock stamps to
  * stamps[64 * workgroup + i]: i = 0 entry, 1 prologue done, 2 channel loop done, 3 end, 4 + c end of chunk c (c < 26),
  * and after tai_conv3x3_wino_timeline_skip(7) 30 + 16 * c + g end of MFMA group g of chunk c (c < 2).  stamps holds

@@ -229,3 +229,24 @@ def test_training_form_gradients_match_autograd_of_conv2d(act, transposed):
     for got, ref, tol in ((y, yd, 1e-5), (gx, rx, 2e-4), (gw, rw, 2e-4), (gb, rb, 2e-4)):
         err = (got.double() - ref).abs().max().item() / (1 + ref.abs().max().item())
         assert err <= tol, err
+
+
+@pytest.mark.parametrize('shape', [(8, 64, 128, 32, 32), (3, 24, 256, 12, 20), (2, 130, 1024, 16, 16)])
+def test_tall_workgroup_shape_gives_the_same_bits(shape):
+    """K a multiple of 128: the 128-channel x 32-tile workgroup shape sums in the same order as the 64 x 64 one."""
+    from video_frame_inpainting_amd import _native
+    L = _native.lib()
+    N, C, K, H, W = shape
+    g = torch.Generator().manual_seed(K + C)
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    w = (torch.randn(K, C, 3, 3, generator=g) * 0.05).cuda()
+    b = torch.randn(K, generator=g).cuda()
+    try:
+        L.tai_conv3x3_wino_set_tall(0)
+        ref = _wino(x, w, b, 'relu')
+        L.tai_conv3x3_wino_set_tall(1)
+        got = _wino(x, w, b, 'relu')
+    finally:
+        L.tai_conv3x3_wino_set_tall(1)
+    assert torch.equal(got, ref)
+    _check(x, w, b, 'relu')

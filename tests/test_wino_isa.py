@@ -30,10 +30,11 @@ def _kernel_bodies(asm, mangled_prefix):
         yield name, asm[i:asm.find('.end_amdhsa_kernel', i)].splitlines()
 
 
+@pytest.mark.parametrize('kernel,dmas', [('7conv3x3', 8), ('12conv3x3_tall', 16)])
 @pytest.mark.parametrize('parts', [0, 1])
-def test_counted_waits_match_the_loads_behind_the_last_dma(device_asm, parts):
-    # conv3x3<ACT 1, DBG 0, SKIP 0, PARTS parts>: the instantiations the product launches
-    prefix = '_ZN4wino7conv3x3ILi1ELi0ELi0ELi%dE' % parts
+def test_counted_waits_match_the_loads_behind_the_last_dma(device_asm, parts, kernel, dmas):
+    # conv3x3<ACT 1, DBG 0, SKIP 0, PARTS parts> and its 128 x 32 twin: the instantiations the product launches
+    prefix = '_ZN4wino%sILi1ELi0ELi0ELi%dE' % (kernel, parts)
     found = 0
     for name, lines in _kernel_bodies(device_asm, prefix):
         found += 1
@@ -46,7 +47,7 @@ def test_counted_waits_match_the_loads_behind_the_last_dma(device_asm, parts):
         for s, w in zip(dma_segs[1:3], waits[1:3]):
             last = max(n for n, l in enumerate(s) if 'global_load_lds_dwordx4' in l)
             behind = sum(1 for l in s[last:] if re.search(r'\bbuffer_load_dword', l))
-            assert sum(1 for l in s if 'global_load_lds_dwordx4' in l) == 8
+            assert sum(1 for l in s if 'global_load_lds_dwordx4' in l) == dmas
             assert behind == w == 12, (name, behind, w)
         # no register spills in the channel loop (they would sit on the MFMA critical path)
         for s in dma_segs[1:3]:

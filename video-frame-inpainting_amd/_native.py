@@ -76,6 +76,8 @@ def lib():
     L.tai_conv3x3_wino_forward_maxpool.restype = I
     L.tai_conv3x3_wino_forward_window.argtypes = [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, V]
     L.tai_conv3x3_wino_forward_window.restype = I
+    L.tai_conv3x3_wino_set_tall.argtypes = [I]
+    L.tai_conv3x3_wino_set_tall.restype = I
     L.tai_conv3x3_wino_forward_parts.argtypes = [P, I, P, P, P, I, I, I, I, I, I, V]
     L.tai_conv3x3_wino_forward_parts.restype = I
     L.tai_conv3x3_wino_forward_timeline.argtypes = [P, P, P, P, I, I, I, I, I, P, V]

@@ -385,6 +385,8 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
 static int wino_forward_impl(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C,
                              int K, int H, int W, int act, void* hip_stream, long long* stamps, float* ypool = nullptr,
                              int in_h = 0, int in_w = 0, int in_oy = 0, int in_ox = 0);
+static int g_wino_tall = 1;            // 1: use the 128 x 32 workgroup shape when K is a multiple of 128
+int tai_conv3x3_wino_set_tall(int on) { const int prev = g_wino_tall; g_wino_tall = on ? 1 : 0; return prev; }
 static int g_wino_timeline_skip = 0;   // timeline launches only: loop parts left out (wino_conv.hip.inc, SKIP)
 int tai_conv3x3_wino_timeline_skip(int level) { g_wino_timeline_skip = level; return 0; }
 
@@ -445,6 +447,7 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
     const long long tiles = (long long)N * (H / 2) * (W / 2);
     const long long tblocks = (tiles + wino::TN - 1) / wino::TN;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const bool tall = !stamps && Kpad % wino::TTM == 0 && g_wino_tall != 0;
 #define TAI_LAUNCH_WINO(A, D, ...)                                                                                     \
     do {                                                                                                               \
         if (int rc = allow_lds(wino::conv3x3<A, D, ##__VA_ARGS__>, wino::LDS_BYTES)) return rc;                          \
@@ -457,6 +460,21 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
     else if (stamps && g_wino_timeline_skip == 7) TAI_LAUNCH_WINO(1, 2, 0);
     else if (stamps && g_wino_timeline_skip == 5) TAI_LAUNCH_WINO(1, 1, 5);
     else if (stamps) TAI_LAUNCH_WINO(1, 1);
+    else if (tall) {
+        // 128-channel x 32-tile workgroups (half the patch transform and LDS writes per MFMA) when K allows
+        const long long ttb = (tiles + wino::TTN - 1) / wino::TTN;
+        const int tkb = Kpad / wino::TTM;
+#define TAI_LAUNCH_WINO_TALL(A, P)                                                                                      \
+    do {                                                                                                               \
+        if (int rc = allow_lds(wino::conv3x3_tall<A, 0, 0, P>, wino::TLDS_BYTES)) return rc;                           \
+        hipLaunchKernelGGL((wino::conv3x3_tall<A, 0, 0, P>), dim3((unsigned)(ttb * tkb)), dim3(256), wino::TLDS_BYTES, s, \
+                           xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, Kpad, \
+                           nchunks, tkb, stamps);                                                                      \
+    } while (0)
+        if (nparts > 1) { if (act == 0) TAI_LAUNCH_WINO_TALL(0, 1); else if (act == 1) TAI_LAUNCH_WINO_TALL(1, 1); else TAI_LAUNCH_WINO_TALL(2, 1); }
+        else { if (act == 0) TAI_LAUNCH_WINO_TALL(0, 0); else if (act == 1) TAI_LAUNCH_WINO_TALL(1, 0); else TAI_LAUNCH_WINO_TALL(2, 0); }
+#undef TAI_LAUNCH_WINO_TALL
+    }
     else if (nparts > 1 && act == 0) TAI_LAUNCH_WINO(0, 0, 0, 1);
     else if (nparts > 1 && act == 1) TAI_LAUNCH_WINO(1, 0, 0, 1);
     else if (nparts > 1) TAI_LAUNCH_WINO(2, 0, 0, 1);
