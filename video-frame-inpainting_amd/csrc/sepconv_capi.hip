@@ -447,34 +447,40 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
     const long long tiles = (long long)N * (H / 2) * (W / 2);
     const long long tblocks = (tiles + wino::TN - 1) / wino::TN;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    const bool tall = !stamps && Kpad % wino::TTM == 0 && g_wino_tall != 0;
+    const bool tall = Kpad % wino::TTM == 0 && g_wino_tall != 0;
 #define TAI_LAUNCH_WINO(A, D, ...)                                                                                     \
     do {                                                                                                               \
         if (int rc = allow_lds(wino::conv3x3<A, D, ##__VA_ARGS__>, wino::LDS_BYTES)) return rc;                          \
         hipLaunchKernelGGL((wino::conv3x3<A, D, ##__VA_ARGS__>), dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::LDS_BYTES, s,  \
                            xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, Kpad, nchunks, kblocks, stamps);                              \
     } while (0)
-    if (stamps && g_wino_timeline_skip == 1) TAI_LAUNCH_WINO(1, 1, 1);
+    if (tall) {
+        // 128-channel x 32-tile workgroups (half the patch transform and LDS writes per MFMA) when K allows
+        const long long ttb = (tiles + wino::TTN - 1) / wino::TTN;
+        const int tkb = Kpad / wino::TTM;
+#define TAI_LAUNCH_WINO_TALL(A, P, ...)                                                                                 \
+    do {                                                                                                               \
+        if (int rc = allow_lds(wino::conv3x3_tall<A, ##__VA_ARGS__>, wino::TLDS_BYTES)) return rc;                     \
+        hipLaunchKernelGGL((wino::conv3x3_tall<A, ##__VA_ARGS__>), dim3((unsigned)(ttb * tkb)), dim3(256), wino::TLDS_BYTES, s, \
+                           xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, Kpad, \
+                           nchunks, tkb, stamps);                                                                      \
+    } while (0)
+        if (stamps && g_wino_timeline_skip == 1) TAI_LAUNCH_WINO_TALL(1, 0, 1, 1);
+        else if (stamps && g_wino_timeline_skip == 2) TAI_LAUNCH_WINO_TALL(1, 0, 1, 2);
+        else if (stamps && g_wino_timeline_skip == 4) TAI_LAUNCH_WINO_TALL(1, 0, 1, 4);
+        else if (stamps && g_wino_timeline_skip == 5) TAI_LAUNCH_WINO_TALL(1, 0, 1, 5);
+        else if (stamps && g_wino_timeline_skip == 7) TAI_LAUNCH_WINO_TALL(1, 0, 2, 0);
+        else if (stamps) TAI_LAUNCH_WINO_TALL(1, 0, 1, 0);
+        else if (nparts > 1) { if (act == 0) TAI_LAUNCH_WINO_TALL(0, 1, 0, 0, 1); else if (act == 1) TAI_LAUNCH_WINO_TALL(1, 1, 0, 0, 1); else TAI_LAUNCH_WINO_TALL(2, 1, 0, 0, 1); }
+        else { if (act == 0) TAI_LAUNCH_WINO_TALL(0, 0, 0, 0, 0); else if (act == 1) TAI_LAUNCH_WINO_TALL(1, 0, 0, 0, 0); else TAI_LAUNCH_WINO_TALL(2, 0, 0, 0, 0); }
+#undef TAI_LAUNCH_WINO_TALL
+    }
+    else if (stamps && g_wino_timeline_skip == 1) TAI_LAUNCH_WINO(1, 1, 1);
     else if (stamps && g_wino_timeline_skip == 2) TAI_LAUNCH_WINO(1, 1, 2);
     else if (stamps && g_wino_timeline_skip == 4) TAI_LAUNCH_WINO(1, 1, 4);
     else if (stamps && g_wino_timeline_skip == 7) TAI_LAUNCH_WINO(1, 2, 0);
     else if (stamps && g_wino_timeline_skip == 5) TAI_LAUNCH_WINO(1, 1, 5);
     else if (stamps) TAI_LAUNCH_WINO(1, 1);
-    else if (tall) {
-        // 128-channel x 32-tile workgroups (half the patch transform and LDS writes per MFMA) when K allows
-        const long long ttb = (tiles + wino::TTN - 1) / wino::TTN;
-        const int tkb = Kpad / wino::TTM;
-#define TAI_LAUNCH_WINO_TALL(A, P)                                                                                      \
-    do {                                                                                                               \
-        if (int rc = allow_lds(wino::conv3x3_tall<A, 0, 0, P>, wino::TLDS_BYTES)) return rc;                           \
-        hipLaunchKernelGGL((wino::conv3x3_tall<A, 0, 0, P>), dim3((unsigned)(ttb * tkb)), dim3(256), wino::TLDS_BYTES, s, \
-                           xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, Kpad, \
-                           nchunks, tkb, stamps);                                                                      \
-    } while (0)
-        if (nparts > 1) { if (act == 0) TAI_LAUNCH_WINO_TALL(0, 1); else if (act == 1) TAI_LAUNCH_WINO_TALL(1, 1); else TAI_LAUNCH_WINO_TALL(2, 1); }
-        else { if (act == 0) TAI_LAUNCH_WINO_TALL(0, 0); else if (act == 1) TAI_LAUNCH_WINO_TALL(1, 0); else TAI_LAUNCH_WINO_TALL(2, 0); }
-#undef TAI_LAUNCH_WINO_TALL
-    }
     else if (nparts > 1 && act == 0) TAI_LAUNCH_WINO(0, 0, 0, 1);
     else if (nparts > 1 && act == 1) TAI_LAUNCH_WINO(1, 0, 0, 1);
     else if (nparts > 1) TAI_LAUNCH_WINO(2, 0, 0, 1);
