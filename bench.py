@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark of the bi-TAI hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1: this process starts the N rank processes itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Metric (BASELINE.json): inpainted frames/sec at 128x128, K=F=5, T=5.  Workload = configs[1]: TAI_gray inference, batch
 32 clips per GPU, hipGraph-replayed forward, fp32 (the reference's arithmetic type; no reduced precision anywhere),
-seeded synthetic clips and seeded xavier weights (no network for datasets / checkpoints).  A step is one forward of the
+seeded synthetic clips and seeded non-trivial weights AND biases (synthetic.seeded_init; no network for datasets /
+checkpoints; the reference's zero-bias init makes every prediction a constant gray frame, which is no parity evidence).  A step is one forward of the
 whole model over one batch; N > 1 shards clips over ranks with no data-path collective (weak scaling); the timed region
 is bracketed by barrier + synchronize and the MAX over ranks is reported.  Inputs are resident in HBM before timing.
 
@@ -20,28 +21,37 @@ The JSON line also carries
                 the algorithm needs on the matrix pipe (16 positions x tiles x K x C = direct-convolution flops / 2.25)
                 / summed launch durations from HIP events, against the 157.3 TFLOP/s dense fp32 MFMA peak;
   cpu_baseline  the CPU oracle (oracle/: PyTorch-CPU convs + the C restatement of the sepconv loops) timed on this
-                host's cores on a bounded sample of the same workload (rank 0, N = 1 only) -- a reported baseline, and
-                the parity check of the GPU output against it.
+                host's cores as BASELINE.md section 2 plans it (B = 1 and B = 8, 1 warm-up + 3 timed forwards each,
+                median; sepconv-only CPU time and GB/s; rank 0, N = 1 only) -- a reported baseline;
+  parity        the GPU output against that oracle run on the same 8 full-width clips: per output key max |diff| over
+                max |ref|, distinct gray levels of the uint8 prediction, PSNR / SSIM vs ground truth on both sides.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import video_frame_inpainting_amd as vfi                                    # noqa: E402
-from video_frame_inpainting_amd import _native, metrics, parallel, synthetic  # noqa: E402
-from video_frame_inpainting_amd import separable_convolution as sc          # noqa: E402
-from video_frame_inpainting_amd.graph import GraphedForward                 # noqa: E402
-
 K_, T_, F_, H_, W_, C_ = 5, 5, 5, 128, 128, 1
 _T0 = time.time()
+WEIGHT_SEED = 0
+
+
+def _imports():
+    """torch and the package are imported by the RANK processes only: the parent of a self-launched N-rank run
+    (launch_ranks) must never initialise the GPU."""
+    global np, torch, vfi, _native, metrics, parallel, synthetic, sc, GraphedForward
+    import numpy as np
+    import torch
+    import video_frame_inpainting_amd as vfi
+    from video_frame_inpainting_amd import _native, metrics, parallel, synthetic
+    from video_frame_inpainting_amd import separable_convolution as sc
+    from video_frame_inpainting_amd.graph import GraphedForward
 
 
 def log(msg):
@@ -96,7 +106,11 @@ def sepconv_roofline(device, B, iters=200, warmup=20):
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
-            traffic = rec.get('hbm_bytes_per_launch') if rec.get('shape') == [B, C_, H_, W_] else None
+            # the committed counter summary counts as evidence only for the library version and default kernel it
+            # was collected on: anything else reports null rather than a stale number
+            same = (rec.get('shape') == [B, C_, H_, W_] and rec.get('library_version') == _native.lib().tai_sepconv_version()
+                    and rec.get('forward_variant') == _native.lib().tai_sepconv_default_forward_variant(C_, W_, ks))
+            traffic = rec.get('hbm_bytes_per_launch') if same else None
         except Exception:
             traffic = None
     return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -170,42 +184,141 @@ def host_cpu_share(cap=16):
     return max(1, min(n, cap))
 
 
-def cpu_baseline_and_parity(model, device, n_clips=16):
-    """Oracle forward on the host cores for a bounded sample (n_clips clips of the workload), and GPU-vs-oracle parity."""
+def _median_time(fn, n):
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        out = fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), ts, out
+
+
+def cpu_baseline_and_parity(model, device, timed=3):
+    """the CPU oracle at B = 1 and B = 8 (1 warm-up + `timed` forwards each, median), the
+    sepconv loops alone, and GPU-vs-oracle parity on the B = 8 clips (full width, seeded weights and biases)."""
     from oracle import sepconv_oracle, tai_oracle
     cores = host_cpu_share()
     torch.set_num_threads(cores)
     sepconv_oracle.set_num_threads(cores)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    n_clips = 8
     clips = synthetic.make_clips(n_clips, K_ + T_ + F_, C_, H_, W_, synthetic.SEEDS['cfg1'])
     P, GT, Fo = (torch.from_numpy(x) for x in synthetic.split_clip(clips, K_, T_, F_))
+    per_b = {}
     with torch.no_grad():
-        log('cpu baseline: warm-up forward of the oracle on %d threads' % cores)
-        tai_oracle.tai_forward(sd, C_, 5, 51, T_, P[:1], Fo[:1])          # warm-up (thread pools, allocator)
-        log('cpu baseline: timed forward (%d clips)' % n_clips)
-        t0 = time.time()
-        ref = tai_oracle.tai_forward(sd, C_, 5, 51, T_, P, Fo)
-        dt = time.time() - t0
-        log('cpu baseline: %.1f s' % dt)
+        for B in (1, n_clips):
+            fwd = lambda: tai_oracle.tai_forward(sd, C_, 5, 51, T_, P[:B], Fo[:B])
+            fwd()                                                               # warm-up (thread pools, primitive caches)
+            med, ts, ref = _median_time(fwd, timed)
+            per_b[B] = {'frames_per_s': round(B * T_ / med, 3), 'median_s': round(med, 3), 'times_s': [round(t, 3) for t in ts]}
+            log('cpu baseline: B=%d  %s s  -> %.2f frames/s' % (B, per_b[B]['times_s'], per_b[B]['frames_per_s']))
         out = model(T_, P.to(device), Fo.to(device))
-    diff = (out['pred'].cpu() - ref['pred']).abs()
-    p_gpu, s_gpu, _ = metrics.compute_errors(out['pred'].cpu().numpy(), GT.numpy())
-    p_cpu, s_cpu, _ = metrics.compute_errors(ref['pred'].numpy(), GT.numpy())
-    mse = float(((out['pred'].cpu() - ref['pred']) ** 2).mean())
+    # the sepconv loops alone (the C restatement of .cu:19-47) at [8,1,128,128]
+    ks = 51
+    g = torch.Generator().manual_seed(7)
+    s_in = (torch.rand(n_clips, C_, H_ + ks - 1, W_ + ks - 1, generator=g) * 2 - 1).numpy()
+    s_v = (torch.randn(n_clips, ks, H_, W_, generator=g) * 0.1).numpy()
+    s_h = (torch.randn(n_clips, ks, H_, W_, generator=g) * 0.1).numpy()
+    sepconv_oracle.forward(s_in, s_v, s_h, ks)
+    s_med, s_ts, _ = _median_time(lambda: sepconv_oracle.forward(s_in, s_v, s_h, ks), timed)
+    s_bytes = sc.forward_bytes(n_clips, C_, H_, W_, ks)
     try:
         cpu_model = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
     except Exception:
         cpu_model = 'unknown'
-    base = {'value': round(n_clips * T_ / dt, 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': 'TAI_gray full width, %d clips of 128x128 K=F=5 T=5, 1 warm-up + 1 timed forward of the CPU oracle '
-                      '(torch CPU convs + C/OpenMP sepconv), %.1f s' % (n_clips, dt),
-            'cpu_model': cpu_model, 'torch_threads': torch.get_num_threads()}
-    parity = {'max_abs_pred': float(diff.max()), 'rms_pred': float(np.sqrt(mse)),
+    cpu_s = sum(sum(v['times_s']) for v in per_b.values()) + sum(s_ts)
+    base = {'value': per_b[n_clips]['frames_per_s'], 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': 'TAI_gray full width, 128x128 K=F=5 T=5: CPU oracle (torch CPU convs + C/OpenMP sepconv) at B=1 and B=8, '
+                      '1 warm-up + %d timed forwards each, median; value = B=8; %.0f s of timed CPU work' % (timed, cpu_s),
+            'b1': per_b[1], 'b8': per_b[n_clips],
+            'sepconv_only': {'shape': [n_clips, C_, H_, W_], 'median_ms': round(s_med * 1e3, 2),
+                             'gb_per_s': round(s_bytes / s_med / 1e9, 2), 'algorithmic_bytes': s_bytes},
+            'cpu_model': cpu_model, 'os_cpu_count': os.cpu_count(), 'sched_affinity': len(os.sched_getaffinity(0)),
+            'torch_threads': torch.get_num_threads()}
+
+    keys = ('pred', 'pred_forward', 'pred_backward', 'interp_net_outputs_1', 'interp_net_outputs_2')
+    rel = {k: float((out[k].cpu() - ref[k]).abs().max() / ref[k].abs().max()) for k in keys}
+    pred_gpu, pred_cpu = out['pred'].cpu().numpy(), ref['pred'].numpy()
+    p_gpu, s_gpu, _ = metrics.compute_errors(pred_gpu, GT.numpy())
+    p_cpu, s_cpu, _ = metrics.compute_errors(pred_cpu, GT.numpy())
+    mse = float(((pred_gpu - pred_cpu) ** 2).mean())
+    u8_gpu, u8_cpu = metrics.to_uint8(pred_gpu), metrics.to_uint8(pred_cpu)
+    parity = {'clips': n_clips, 'weights': 'synthetic.seeded_init(seed %d): N(0, 1/fan_in) weights, N(0, 0.01) biases' % WEIGHT_SEED,
+              'max_abs_over_max_ref': {k: float('%.3g' % v) for k, v in rel.items()},
+              'max_abs_ref_pred': float(np.abs(pred_cpu).max()),
+              'max_abs_pred': float(np.abs(pred_gpu - pred_cpu).max()), 'rms_pred': float(np.sqrt(mse)),
               'psnr_gpu_vs_cpu_pred_db': float(10 * np.log10(4.0 / mse)) if mse > 0 else float('inf'),
+              'uint8_gray_levels_gpu': int(len(np.unique(u8_gpu))), 'uint8_gray_levels_cpu': int(len(np.unique(u8_cpu))),
+              'uint8_pixels_differing': int((u8_gpu != u8_cpu).sum()), 'uint8_pixels': int(u8_gpu.size),
               'psnr_vs_gt_gpu_db': float(p_gpu.mean()), 'psnr_vs_gt_cpu_db': float(p_cpu.mean()),
+              'psnr_vs_gt_per_frame_spread_db': float(p_cpu.max() - p_cpu.min()),
               'max_abs_psnr_delta_db': float(np.max(np.abs(p_gpu - p_cpu))),
               'max_abs_ssim_delta': float(np.max(np.abs(s_gpu - s_cpu)))}
     return base, parity
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU, the
+    environment torch.distributed.run would give them), wait, and exit non-zero if any of them failed.  This parent has
+    not imported torch and never touches the GPU; rank 0 prints the JSON line on the inherited stdout."""
+    port = os.environ.get('MASTER_PORT') or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=port, TAI_BENCH_RANK_PROCESS='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+                break
+    if failed is None:
+        failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:                   # the exact children started above, nothing else
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        print('[bench] rank %d exited with code %s: run failed' % failed, file=sys.stderr, flush=True)
+        return 1
+    return 0
+
+
+def rehearse_launch(args):
+    """CPU rehearsal of the N-rank launch, rendezvous, barrier and max-over-ranks reduction (gloo, no GPU, no model):
+    what tests/test_bench_launch.py drives.  Prints a line marked "rehearsal" -- never a measurement."""
+    import torch
+    import torch.distributed as dist
+    from video_frame_inpainting_amd import parallel
+    rank, world, _ = parallel.init_from_env(backend='gloo')
+    assert world == args.gpus, (world, args.gpus)
+    if os.environ.get('TAI_BENCH_FAIL_RANK') == str(rank):
+        sys.exit(3)
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([1.0 + rank], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({'rehearsal': True, 'n_gpus': world, 'ranks': world, 'backend': 'gloo', 'max_dt': float(dt.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -217,10 +330,17 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of the hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--miopen-find', action='store_true', help='let MIOpen benchmark its algorithms during warm-up')
+    ap.add_argument('--rehearse-launch', action='store_true', help='CPU/gloo rehearsal of the rank launch only (tests)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.rehearse_launch:
+        return rehearse_launch(args)
+
+    _imports()
     rank, world, local_rank = parallel.init_from_env()
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d' % (args.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     _native.lib()                                   # fail loudly if the HIP library is missing
     device = torch.device('cuda', local_rank)
@@ -228,11 +348,11 @@ def main():
     torch.backends.cudnn.benchmark = args.miopen_find     # MIOpen exhaustive find is minutes of search: opt-in
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
+    backend = torch.distributed.get_backend() if world > 1 else None
 
     log('rank %d/%d on %s' % (rank, world, torch.cuda.get_device_name(device)))
-    torch.manual_seed(0)
     model = vfi.create_model('TAI_gray')
-    model.apply(vfi.util.weights_init)
+    synthetic.seeded_init(model, WEIGHT_SEED)       # identical on every rank; weights AND biases non-trivial
     model.to(device).eval()
     B = args.batch
     clips = synthetic.make_clips(B, K_ + T_ + F_, C_, H_, W_, synthetic.SEEDS['cfg2'] + rank)
@@ -272,8 +392,7 @@ def main():
     dt = time.perf_counter() - t0
     log('timed %d steps: %.3f s' % (args.steps, dt))
     if world > 1:
-        on_gloo = torch.distributed.get_backend() == 'gloo'
-        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if on_gloo else device)
+        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if backend == 'gloo' else device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -288,7 +407,8 @@ def main():
         'config': {'workload': 'configs[1]: bi-TAI (TAI_gray) 128x128 grayscale K=F=5 T=5 inference, batch %d per GPU, '
                                'sepconv HIP kernels + %s' % (B, 'eager launches' if args.no_graph else 'hipGraph replay'),
                    'clips_per_gpu': B, 'global_clips': world * B, 'parallelism': 'clip-sharded x%d, no collective' % world,
-                   'weights': 'seeded xavier-normal init (torch.manual_seed(0))'},
+                   'ranks': world, 'backend': ('rccl (torch.distributed "nccl")' if backend == 'nccl' else backend),
+                   'weights': 'seeded N(0, 1/fan_in) weights and N(0, 0.01) biases (synthetic.seeded_init, seed %d)' % WEIGHT_SEED},
     }
     if rank == 0:
         line['roofline'] = sepconv_roofline(device, B)
@@ -300,7 +420,7 @@ def main():
             base, parity = cpu_baseline_and_parity(model, device)
             line['cpu_baseline'] = base
             line['parity'] = parity
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

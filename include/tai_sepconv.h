@@ -126,7 +126,8 @@ int tai_conv3x3_wino_set_tall(int on);
  * stamps[64 * workgroup + i]: i = 0 entry, 1 prologue done, 2 channel loop done, 3 end, 4 + c end of chunk c (c < 26),
  * and after tai_conv3x3_wino_timeline_skip(7) 30 + 16 * c + g end of MFMA group g of chunk c (c < 2).  stamps holds
  * 64 * workgroups int64.  tai_conv3x3_wino_timeline_skip(level): 0 the full kernel; 1, 2, 5 leave parts of it out to
- * time what remains (results are then wrong); affects timeline launches only. */
+ * time what remains (results are then wrong); affects timeline launches only, and only in the tools build of the library
+ * (-DTAI_TIMING_VARIANTS): the shipped library accepts level 0 alone. */
 int tai_conv3x3_wino_forward_timeline(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H,
                                       int W, long long* stamps, void* hip_stream);
 int tai_conv3x3_wino_timeline_skip(int level);
@@ -142,9 +143,12 @@ int tai_conv3x3_wino_timeline_skip(int level);
  *       given a contiguous eighth of the tile list,
  *   14/15 = type-A waves that load their taps once and run the row loop once per channel (8- / 4-wave workgroups;
  *       15 is the default for C > 1).
- *   Values >= 100 are timing experiments and may produce wrong results.
+ *   Values >= 100 (timing experiments that produce wrong results) exist only in the tools build of the library
+ *   (-DTAI_TIMING_VARIANTS, build/libtai_sepconv_timing.so); the shipped library rejects them with TAI_SEPCONV_EINVAL.
  * Returns the previous value. */
 int tai_sepconv_set_forward_variant(int variant);
+/* The variant `0 = automatic` resolves to for a frame of C channels, width W and filter size ks. */
+int tai_sepconv_default_forward_variant(int C, int W, int ks);
 
 /* grad_input kernel of tai_sepconv_backward: 0 = automatic (LDS row-scatter when ks == 51, W % 4 == 0, C in {1, 3};
  * accumulates with float atomics: last bits depend on arrival order), 1 = bounds-checked gather (any shape, bit-

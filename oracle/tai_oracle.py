@@ -178,8 +178,30 @@ def upsample_block(sd, p, x):
     return F.relu(_conv(sd, p + '1', _up2(x), 1))
 
 
+class SepconvFunction(torch.autograd.Function):
+    """SeparableConvolution (SeparableConvolution.py:6-92) on the C oracle: forward = updateOutput (.cu:19-47),
+    backward = updateGradV / updateGradH / updateGradI (.cu:49-162), returning (gI, gV, gH, None) as :89 does."""
+
+    @staticmethod
+    def forward(ctx, inp_padded, vertical, horizontal, ks):
+        ctx.save_for_backward(inp_padded, vertical, horizontal)
+        ctx.ks = ks
+        out = sepconv_oracle.forward(inp_padded.detach().numpy(), vertical.detach().numpy(), horizontal.detach().numpy(), ks)
+        return torch.from_numpy(out).to(inp_padded.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        inp_padded, vertical, horizontal = ctx.saved_tensors
+        gI, gV, gH = sepconv_oracle.backward(grad_output.contiguous().numpy(), inp_padded.detach().numpy(),
+                                             vertical.detach().numpy(), horizontal.detach().numpy(), ctx.ks)
+        return torch.from_numpy(gI), torch.from_numpy(gV), torch.from_numpy(gH), None
+
+
 def sepconv(inp_padded, vertical, horizontal, ks, f64=False):
-    """SeparableConvolution.forward, SeparableConvolution.py:11-52 via the C oracle."""
+    """SeparableConvolution.forward, SeparableConvolution.py:11-52 via the C oracle (differentiable through
+    SepconvFunction when any operand requires grad: the training leg, oracle/train_oracle.py)."""
+    if torch.is_grad_enabled() and (inp_padded.requires_grad or vertical.requires_grad or horizontal.requires_grad):
+        return SepconvFunction.apply(inp_padded.contiguous(), vertical.contiguous(), horizontal.contiguous(), ks)
     out = sepconv_oracle.forward(inp_padded.detach().cpu().numpy(), vertical.detach().cpu().numpy(),
                                  horizontal.detach().cpu().numpy(), ks, f64=f64)
     return torch.from_numpy(out).to(inp_padded.dtype)

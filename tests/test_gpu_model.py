@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import video_frame_inpainting_amd as vfi
 from video_frame_inpainting_amd import metrics, synthetic
@@ -42,24 +43,88 @@ def test_matches_reference_golden_run(golden_dir, tag):
         np.testing.assert_allclose(out[k].cpu().numpy(), z['out/' + k], rtol=0, atol=2e-4, err_msg=k)
 
 
+REL_TOL = 1e-4      # per output key: max |gpu - oracle| <= REL_TOL * max |oracle|  (fp32, different summation orders)
+
+
+def _assert_matches_oracle(out, ref, GT, name=''):
+    """Outputs within REL_TOL of the oracle relative to each key's own magnitude, AND the comparison is about something:
+    the uint8 prediction spans many gray levels, PSNR vs ground truth differs between frames, and PSNR / SSIM vs ground
+    truth agree between GPU and oracle (0.01 dB / 1e-4)."""
+    for k in KEYS:
+        scale = float(ref[k].abs().max())
+        assert scale > 0.05, (name, k, scale)                 # a near-zero reference would make the check vacuous
+        err = float((out[k].cpu() - ref[k]).abs().max())
+        assert err <= REL_TOL * scale, (name, k, err, scale)
+    pred_gpu, pred_cpu = out['pred'].cpu().numpy(), ref['pred'].numpy()
+    assert len(np.unique(metrics.to_uint8(pred_gpu))) > 50, name
+    p_gpu, s_gpu, _ = metrics.compute_errors(pred_gpu, GT.numpy())
+    p_cpu, s_cpu, _ = metrics.compute_errors(pred_cpu, GT.numpy())
+    if p_cpu.size > 1:
+        assert p_cpu.max() - p_cpu.min() > 0.05, (name, p_cpu)       # frames differ: the deltas below carry information
+    assert np.max(np.abs(p_gpu - p_cpu)) <= 0.01, (name, p_gpu, p_cpu)     # dB
+    assert np.max(np.abs(s_gpu - s_cpu)) <= 1e-4, (name, s_gpu, s_cpu)
+
+
 def test_cfg1_shape_matches_cpu_oracle_and_psnr_parity():
-    # BASELINE config 0 geometry (TAI_gray, 128x128 gray, K=F=5, T=5, B=1) at reduced width so the CPU side takes seconds
-    torch.manual_seed(0)
-    m = vfi.TAIFillInModel(8, 1, 3, 51, num_block=5, kf_dim=4)
-    m.apply(vfi.util.weights_init)
+    # BASELINE config 0 geometry (TAI_gray, 128x128 gray, K=F=5, T=5, B=1) at reduced width so the CPU side takes seconds;
+    # seeded weights AND biases (zero biases give taps ~1e-4 and constant-gray predictions: no evidence)
+    m = synthetic.seeded_init(vfi.TAIFillInModel(8, 1, 3, 51, num_block=5, kf_dim=4), 0)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     clips = synthetic.make_clips(1, 15, 1, 128, 128, synthetic.SEEDS['cfg1'])
     P, GT, Fo = (torch.from_numpy(x) for x in synthetic.split_clip(clips, 5, 5, 5))
     with torch.no_grad():
         ref = tai_oracle.tai_forward(sd, 1, 5, 51, 5, P, Fo)
         out = m.to(DEV).eval()(5, P.to(DEV), Fo.to(DEV))
-    for k in KEYS:
-        d = (out[k].cpu() - ref[k]).abs()
-        assert float(d.max()) <= 2e-4, (k, float(d.max()))
-    p_gpu, s_gpu, _ = metrics.compute_errors(out['pred'].cpu().numpy(), GT.numpy())
-    p_cpu, s_cpu, _ = metrics.compute_errors(ref['pred'].numpy(), GT.numpy())
-    assert np.max(np.abs(p_gpu - p_cpu)) <= 0.01          # dB
-    assert np.max(np.abs(s_gpu - s_cpu)) <= 1e-4
+    _assert_matches_oracle(out, ref, GT, 'cfg1 shape')
+
+
+def test_full_width_tai_gray_matches_cpu_oracle():
+    """The model BASELINE's headline is quoted on -- TAI_gray, gf_dim 64, 128x128, K=F=T=5 -- against the CPU oracle on two
+    clips: every 3x3 layer runs on the Winograd-MFMA kernels at their production shapes (the reduced-width tests fall
+    below conv_ops.WINO_MIN_WORKGROUPS on most layers), the 5x5 / 7x7 layers on the shifted-stack path."""
+    m = synthetic.seeded_init(vfi.create_model('TAI_gray'), 0)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    clips = synthetic.make_clips(2, 15, 1, 128, 128, synthetic.SEEDS['cfg2'])
+    P, GT, Fo = (torch.from_numpy(x) for x in synthetic.split_clip(clips, 5, 5, 5))
+    with torch.no_grad():
+        ref = tai_oracle.tai_forward(sd, 1, 5, 51, 5, P, Fo)
+        m.to(DEV).eval()
+        out = m(5, P.to(DEV), Fo.to(DEV))
+        _assert_matches_oracle(out, ref, GT, 'full width, eager')
+        g = GraphedForward(m, 5, P.to(DEV), Fo.to(DEV))
+        _assert_matches_oracle(g(), ref, GT, 'full width, hipGraph replay')
+
+
+def test_derived_weights_follow_in_place_weight_writes():
+    """conv_ops caches Winograd-domain / flipped weights per tensor version: a write that moves the version
+    counter is seen by itself; a write through .data needs conv_ops.invalidate_derived (weights_init, the replica
+    broadcast and the environments' load call it)."""
+    from video_frame_inpainting_amd import conv_ops
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1).to(DEV)
+    convt = torch.nn.ConvTranspose2d(64, 64, 3, padding=1).to(DEV)
+    x = torch.randn(8, 64, 64, 64, device=DEV)
+
+    def check():
+        with torch.no_grad():
+            got = conv_ops.conv_bias_act(x, conv.weight, conv.bias, 1, 'relu')
+            want = torch.relu(F.conv2d(x, conv.weight, conv.bias, padding=1))
+            assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+            got = conv_ops.conv_bias_act(x, convt.weight, convt.bias, 1, None, transposed=True)
+            want = F.conv_transpose2d(x, convt.weight, convt.bias, padding=1)
+            assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    check()
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+        convt.weight.add_(0.01)
+    check()                                     # version counter moved: rebuilt without help
+    conv.weight.data.mul_(-0.5)                 # neither the version counter nor the pointer moves
+    convt.weight.data.mul_(3.0)
+    conv_ops.invalidate_derived(conv)
+    conv_ops.invalidate_derived(convt)
+    check()
+    conv.apply(vfi.util.weights_init)           # the package's own re-initialisation is seen without an explicit call
+    check()
 
 
 def test_direction_fusion_and_graph_replay_change_nothing():
@@ -157,9 +222,7 @@ def test_ablation_models_on_gpu_match_reference_runs(golden_dir):
 
 
 def _tiny(c_dim, num_block, seed):
-    torch.manual_seed(seed)
-    m = vfi.TAIFillInModel(8, c_dim, 3, 51, num_block=num_block, kf_dim=4)
-    m.apply(vfi.util.weights_init)
+    m = synthetic.seeded_init(vfi.TAIFillInModel(8, c_dim, 3, 51, num_block=num_block, kf_dim=4), seed)
     return m, {k: v.clone() for k, v in m.state_dict().items()}
 
 
@@ -178,10 +241,7 @@ def test_other_baseline_config_shapes_match_cpu_oracle(name, c_dim, num_block, H
         out = m.to(DEV).eval()(T, P.to(DEV), Fo.to(DEV))
     for k in KEYS:
         assert out[k].shape == ref[k].shape == (1, T, c_dim, H, W)
-        assert float((out[k].cpu() - ref[k]).abs().max()) <= 2e-4, (name, k)
-    p_gpu, s_gpu, _ = metrics.compute_errors(out['pred'].cpu().numpy(), GT.numpy())
-    p_cpu, s_cpu, _ = metrics.compute_errors(ref['pred'].numpy(), GT.numpy())
-    assert np.max(np.abs(p_gpu - p_cpu)) <= 0.01 and np.max(np.abs(s_gpu - s_cpu)) <= 1e-4
+    _assert_matches_oracle(out, ref, GT, name)
 
 
 def test_predict_and_train_drivers_run_end_to_end(tmp_path, monkeypatch):

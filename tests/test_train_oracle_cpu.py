@@ -1,0 +1,94 @@
+"""The oracle's training leg (oracle/train_oracle.py) against the product's CPU-runnable pieces: the spectral-norm
+discriminator (weights mutated in place by every window of every forward), the window labels, GDL against the
+reference-run golden vectors, and the oracle's sepconv autograd Function against fp64 autograd of an independent
+formulation.  (The generator itself has no CPU form in the product: its training parity is tests/test_gpu_training.py.)"""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import tai_oracle, train_oracle
+from video_frame_inpainting_amd import synthetic
+from video_frame_inpainting_amd.sn_discriminator import SNDiscriminator
+
+
+def _disc_pair(df_dim=4, Ip=3, window=3, size=32):
+    disc = synthetic.seeded_init(SNDiscriminator((size, size), 1, window, df_dim, Ip), 5)
+    g = torch.Generator().manual_seed(6)
+    u = {}
+    for name, m in disc.named_modules():
+        if hasattr(m, 'Ip'):
+            u[name] = torch.randn(1, m.weight.size(0), generator=g)
+            m.u = u[name].clone()
+    state = train_oracle.DiscriminatorState(disc.state_dict(), u, Ip, window)
+    return disc, state
+
+
+def test_discriminator_state_matches_module_over_two_forwards_and_gradients():
+    disc, state = _disc_pair()
+    x = torch.randn(2, 7, 1, 32, 32, generator=torch.Generator().manual_seed(1))
+    y = torch.randn(2, 7, 1, 32, 32, generator=torch.Generator().manual_seed(2))
+    # first evaluation (as inside the generator loss), then two tracked ones (fake, real) whose gradients accumulate
+    h0, r0 = disc(x), state.forward(x)
+    np.testing.assert_allclose(h0.detach().numpy(), r0.numpy(), rtol=1e-5, atol=1e-6)
+    disc.zero_grad()
+    loss = F.binary_cross_entropy_with_logits(disc(x), torch.zeros(2, 5)) + F.binary_cross_entropy_with_logits(disc(y), torch.ones(2, 5))
+    loss.backward()
+    state.uses = []
+    bias = {k: v.clone().requires_grad_(True) for k, v in state.sd.items() if k.endswith('.bias')}
+    rl = F.binary_cross_entropy_with_logits(state.forward(x, True, bias), torch.zeros(2, 5)) + \
+        F.binary_cross_entropy_with_logits(state.forward(y, True, bias), torch.ones(2, 5))
+    assert abs(float(loss.detach()) - float(rl.detach())) <= 1e-6 * abs(float(rl.detach()))
+    leaves = [w for _, w in state.uses] + list(bias.values())
+    grads = torch.autograd.grad(rl, leaves)
+    acc = {}
+    for (k, _), g in zip(state.uses, grads):
+        acc[k] = acc.get(k, 0) + g
+    for k, g in zip(bias, grads[len(state.uses):]):
+        acc[k] = g
+    for k, p in disc.named_parameters():
+        np.testing.assert_allclose(p.grad.numpy(), acc[k].numpy(), rtol=1e-4, atol=1e-7 * float(acc[k].abs().max()) + 1e-12, err_msg=k)
+        np.testing.assert_allclose(p.detach().numpy(), state.sd[k].numpy(), rtol=1e-5, atol=1e-7, err_msg=k)   # 3 x 5 renormalisations
+    for name, m in disc.named_modules():
+        if hasattr(m, 'Ip'):
+            np.testing.assert_allclose(m.u.numpy(), state.u[name].numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_fake_labels_follow_the_reference_layout():
+    # environments.py:308-323: ones for the all-real windows at both ends
+    assert train_oracle.fake_labels(5, 5, 5, 3).tolist() == [1, 1, 1] + [0] * 7 + [1, 1, 1]
+    assert train_oracle.fake_labels(2, 1, 2, 3).tolist() == [0, 0, 0]
+    assert train_oracle.fake_labels(4, 2, 3, 3).tolist() == [1, 1, 0, 0, 0, 0, 1]
+    from video_frame_inpainting_amd.environments import L2GDLDiscTrainingEnvironment
+    env = L2GDLDiscTrainingEnvironment.__new__(L2GDLDiscTrainingEnvironment)
+    for K, T, Fn, dt in ((5, 5, 5, 3), (2, 1, 2, 3), (4, 2, 3, 3), (3, 3, 3, 2)):
+        env.K, env.T, env.F, env.disc_t = K, T, Fn, dt
+        assert env.create_fake_labels().tolist() == train_oracle.fake_labels(K, T, Fn, dt).tolist()
+
+
+def test_oracle_gdl_matches_reference_run(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'blocks.npz'))
+    keys = [k for k in z.files if k.startswith('gdl/')]
+    assert keys, 'blocks.npz holds the GDL vectors captured from the reference'
+    got = tai_oracle.gdl(torch.from_numpy(z['gdl/a']), torch.from_numpy(z['gdl/b']))
+    np.testing.assert_allclose(float(got), float(np.asarray(z['gdl/out']).reshape(-1)[0]), rtol=1e-6)
+
+
+def test_sepconv_function_gradients_match_fp64_autograd():
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W, ks = 1, 2, 5, 6, 7
+    inp = torch.randn(B, C, H + ks - 1, W + ks - 1, generator=g)
+    v = torch.randn(B, ks, H, W, generator=g) * 0.3
+    h = torch.randn(B, ks, H, W, generator=g) * 0.3
+    gO = torch.randn(B, C, H, W, generator=g)
+    a, b, c = (t.clone().requires_grad_(True) for t in (inp, v, h))
+    out = tai_oracle.sepconv(a, b, c, ks)
+    out.backward(gO)
+    a64, b64, c64 = (t.double().clone().requires_grad_(True) for t in (inp, v, h))
+    patches = a64.unfold(2, ks, 1).unfold(3, ks, 1)                       # [B,C,H,W,ks,ks]
+    ref = torch.einsum('bcyxij,biyx,bjyx->bcyx', patches, b64, c64)
+    ref.backward(gO.double())
+    np.testing.assert_allclose(out.detach().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    for got, want in ((a.grad, a64.grad), (b.grad, b64.grad), (c.grad, c64.grad)):
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=1e-5)

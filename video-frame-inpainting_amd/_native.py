@@ -27,38 +27,49 @@ def declared_symbols():
     """Function names declared in include/tai_sepconv.h."""
     text = open(HEADER).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(tai_sepconv_\w+)\s*\(', text)))
+    return sorted(set(re.findall(r'\b(tai_\w+)\s*\(', text)))
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> video-frame-inpainting_amd/libtai_sepconv.so (cross-compiles without a GPU)."""
+TIMING_LIB_PATH = os.path.join(_ROOT, 'build', 'libtai_sepconv_timing.so')
+
+
+def build(force=False, verbose=False, timing=False):
+    """hipcc --offload-arch=gfx950 -> video-frame-inpainting_amd/libtai_sepconv.so (cross-compiles without a GPU).
+    ``timing=True`` builds build/libtai_sepconv_timing.so instead: the same sources with -DTAI_TIMING_VARIANTS, i.e. with
+    the timing experiments (forward variants >= 100, Winograd timeline skip levels) that the shipped library leaves out;
+    only tools/ links or loads it."""
+    out = TIMING_LIB_PATH if timing else LIB_PATH
     newest = max(os.path.getmtime(p) for p in SOURCES + [HEADER])
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
-        return LIB_PATH
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+        return out
     gen = os.path.join(_ROOT, 'tools', 'gen_fwd_asm.py')
     if os.path.exists(gen) and os.path.getmtime(gen) > os.path.getmtime(SOURCES[3]):
         subprocess.check_call(['python3', gen], stdout=subprocess.DEVNULL)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-slp-vectorize', '-w',
-           '-I' + os.path.join(_ROOT, 'include'), '-o', LIB_PATH, SOURCES[0]]
+           '-I' + os.path.join(_ROOT, 'include'), '-o', out, SOURCES[0]] + (['-DTAI_TIMING_VARIANTS'] if timing else [])
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out
 
 
 def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH
+    if os.environ.get('TAI_NATIVE_TIMING_LIB') == '1':     # tools/ only: the build with the timing experiments compiled in
+        path = TIMING_LIB_PATH
+    if not os.path.exists(path):
         raise NativeLibraryError(
             '%s is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
-            '(there is no fallback path for the separable convolution)' % LIB_PATH)
+            '(there is no fallback path for the separable convolution)' % path)
     import torch  # noqa: F401  -- load torch's HIP runtime first so this library binds to the same libamdhip64
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     missing = [s for s in declared_symbols() if not hasattr(L, s)]
     if missing:
-        raise NativeLibraryError('%s does not export %s' % (LIB_PATH, missing))
+        raise NativeLibraryError('%s does not export %s' % (path, missing))
     P, I, V = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
     L.tai_sepconv_forward.argtypes = [P, P, P, P, I, I, I, I, I, V]
     L.tai_sepconv_forward.restype = I
@@ -96,6 +107,8 @@ def lib():
     L.tai_bias_act_inplace.restype = I
     L.tai_sepconv_set_forward_variant.argtypes = [I]
     L.tai_sepconv_set_forward_variant.restype = I
+    L.tai_sepconv_default_forward_variant.argtypes = [I, I, I]
+    L.tai_sepconv_default_forward_variant.restype = I
     L.tai_sepconv_set_grad_taps_variant.argtypes = [I]
     L.tai_sepconv_set_grad_taps_variant.restype = I
     L.tai_sepconv_set_grad_input_variant.argtypes = [I]

@@ -25,18 +25,37 @@ def _as_conv_weight(weight, transposed):
     return weight.transpose(0, 1).flip(2, 3) if transposed else weight
 
 
+_EPOCH = [0]
+
+
+def invalidate_derived(module=None):
+    """Drop the cached derived weights (Winograd-domain U, direct-conv layout of a transposed conv) of ``module``'s
+    parameters, or of every weight when ``module`` is None.  The cache notices writes that move the tensor's version
+    counter (optimizer steps, ``load_state_dict``, ``with torch.no_grad(): p.mul_(2)``) by itself; a write through
+    ``p.data`` moves neither the counter nor the pointer (``p.data.normal_()``, ``dist.broadcast(p.data, ...)``, a user's
+    EMA or clipping), so whoever writes that way calls this afterwards -- ``util.weights_init``,
+    ``parallel.broadcast_module_state`` and the environments' ``load`` do."""
+    if module is None:
+        _EPOCH[0] += 1
+        return
+    for p in module.parameters():
+        if hasattr(p, '_tai_derived'):
+            p._tai_derived.clear()
+
+
 def _cached(weight, tag, make):
-    """Derived form of a weight (Winograd-domain U, direct-conv layout of a transposed conv), kept on the tensor object
-    and rebuilt when the weight is modified in place (optimizer step, load_state_dict)."""
+    """Derived form of a weight, kept on the tensor object and rebuilt when the weight's version counter or storage
+    moves, or after ``invalidate_derived``."""
     cache = getattr(weight, '_tai_derived', None)
     if cache is None:
         cache = {}
         weight._tai_derived = cache
     hit = cache.get(tag)
-    if hit is None or hit[0] != weight._version or hit[1] != weight.data_ptr():
-        hit = (weight._version, weight.data_ptr(), make())
+    key = (weight._version, weight.data_ptr(), _EPOCH[0])
+    if hit is None or hit[0] != key:
+        hit = (key, make())
         cache[tag] = hit
-    return hit[2]
+    return hit[1]
 
 
 def _wino_weights(weight, transposed):

@@ -6,6 +6,7 @@
 // allocation or copy on any path, so every call can be captured into a hipGraph.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -22,9 +23,11 @@
 namespace {
 
 thread_local char g_err[256] = "";
-int g_fwd_variant = 0;
-int g_gi_variant = 0;
-int g_vh_variant = 0;   // 0 automatic (fused asm kernel for C == 1 when both gradients are wanted), 1 HIP kernels   // 0 automatic (LDS row-scatter when tileable), 1 force the gather kernel
+// Kernel selectors (benchmarking / tests).  Process-wide; relaxed atomics so a selector flipped by one thread while
+// another launches is a defined (if unordered) read, never a torn one.
+std::atomic<int> g_fwd_variant{0};
+std::atomic<int> g_gi_variant{0};   // 0 automatic, 1 force the gather kernel
+std::atomic<int> g_vh_variant{0};   // 0 automatic (fused asm kernel for C == 1 when both gradients are wanted), 1 HIP kernels
 
 int fail(int code, const char* fmt, const char* what) {
     std::snprintf(g_err, sizeof(g_err), fmt, what);
@@ -47,23 +50,28 @@ bool dims_ok(int B, int C, int H, int W, int ks) {
     return (long long)B * C * Hp * Wp < lim && (long long)B * ks * H * W < lim;
 }
 
-// Raises the kernel's dynamic-LDS limit past the default 64 KiB.  Done once per kernel and size (the attribute sticks),
-// so the steady-state launch path makes no runtime call besides the launch itself.
+// Raises the kernel's dynamic-LDS limit past the default 64 KiB.  The attribute is per DEVICE and sticks, so it is set
+// once per (device, kernel, size) and remembered only after the runtime accepted it: the steady-state launch path makes
+// no runtime call besides hipGetDevice and the launch itself.
 template <typename KernelT>
 int allow_lds(KernelT kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return TAI_SEPCONV_OK;
-    static thread_local const void* done_kernel[32];
-    static thread_local size_t done_bytes[32];
+    constexpr int SLOTS = 64;
+    static thread_local const void* done_kernel[SLOTS];
+    static thread_local size_t done_bytes[SLOTS];
+    static thread_local int done_device[SLOTS];
     static thread_local int n_done = 0;
+    int device = -1;
+    if (hipGetDevice(&device) != hipSuccess) return fail(TAI_SEPCONV_ELAUNCH, "%s", "hipGetDevice");
+    const void* key = reinterpret_cast<const void*>(kernel);
     for (int i = 0; i < n_done; ++i)
-        if (done_kernel[i] == reinterpret_cast<const void*>(kernel) && done_bytes[i] >= bytes) return TAI_SEPCONV_OK;
-    if (n_done < 32) { done_kernel[n_done] = reinterpret_cast<const void*>(kernel); done_bytes[n_done] = bytes; ++n_done; }
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (done_kernel[i] == key && done_device[i] == device && done_bytes[i] >= bytes) return TAI_SEPCONV_OK;
+    const hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) {
         std::snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(lds=%zu): %s", bytes, hipGetErrorString(e));
         return TAI_SEPCONV_ELAUNCH;
     }
+    if (n_done < SLOTS) { done_kernel[n_done] = key; done_bytes[n_done] = bytes; done_device[n_done] = device; ++n_done; }
     return TAI_SEPCONV_OK;
 }
 
@@ -192,26 +200,19 @@ int launch_grad_vh_tiled(const float* gO, const float* in, const float* v, const
 
 extern "C" {
 
-int tai_sepconv_version(void) { return 100; }
+int tai_sepconv_version(void) { return 200; }
 
 const char* tai_sepconv_last_error(void) { return g_err; }
 
-int tai_sepconv_set_forward_variant(int variant) {
-    const int prev = g_fwd_variant;
-    g_fwd_variant = variant;
-    return prev;
-}
+int tai_sepconv_set_forward_variant(int variant) { return g_fwd_variant.exchange(variant, std::memory_order_relaxed); }
 
-int tai_sepconv_set_grad_taps_variant(int variant) {
-    const int prev = g_vh_variant;
-    g_vh_variant = variant;
-    return prev;
-}
+int tai_sepconv_set_grad_taps_variant(int variant) { return g_vh_variant.exchange(variant, std::memory_order_relaxed); }
 
-int tai_sepconv_set_grad_input_variant(int variant) {
-    const int prev = g_gi_variant;
-    g_gi_variant = variant;
-    return prev;
+int tai_sepconv_set_grad_input_variant(int variant) { return g_gi_variant.exchange(variant, std::memory_order_relaxed); }
+
+int tai_sepconv_default_forward_variant(int C, int W, int ks) {
+    const bool tileable = (ks == 51) && (W % 4 == 0);
+    return !tileable ? 1 : (C == 1 ? 16 : 15);
 }
 
 long long tai_sepconv_forward_bytes(int B, int C, int H, int W, int ks) {
@@ -231,10 +232,10 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
     if (!dims_ok(B, C, H, W, ks)) return fail(TAI_SEPCONV_EINVAL, "%s", "bad dimensions");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
 
-    int variant = g_fwd_variant;
+    int variant = g_fwd_variant.load(std::memory_order_relaxed);
     const bool tileable = (ks == 51) && (W % 4 == 0);
     // default: mixed type-A / type-B hand-scheduled kernel for single-channel frames; taps-once channel loop otherwise
-    if (variant == 0) variant = !tileable ? 1 : (C == 1 ? 16 : 15);
+    if (variant == 0) variant = tai_sepconv_default_forward_variant(C, W, ks);
     if (variant != 1 && !tileable)
         return fail(TAI_SEPCONV_EINVAL, "%s", "tiled forward variants need ks == 51 and W % 4 == 0");
     switch (variant) {
@@ -256,12 +257,13 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 11: return fwd_ab_all_channels<1>(input, vertical, horizontal, output, B, C, H, W, s);
         case 12: return fwd_ab_all_channels<2>(input, vertical, horizontal, output, B, C, H, W, s);
         case 13: return fwd_ab_all_channels<3>(input, vertical, horizontal, output, B, C, H, W, s);
-        case 108: return fwd_ab_all_channels<3, 3>(input, vertical, horizontal, output, B, C, H, W, s);
-        case 106: return fwd_ab_all_channels<0, 3>(input, vertical, horizontal, output, B, C, H, W, s);
-        case 107: return fwd_ab_all_channels<2, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 16: return fwd_ab_all_channels<4>(input, vertical, horizontal, output, B, C, H, W, s);
         case 14: return fwd_asm_channel_loop<8>(input, vertical, horizontal, output, B, C, H, W, s);
         case 15: return fwd_asm_channel_loop<4>(input, vertical, horizontal, output, B, C, H, W, s);
+#ifdef TAI_TIMING_VARIANTS   // timing experiments (wrong results by design): tools/ build only, never in the shipped library
+        case 108: return fwd_ab_all_channels<3, 3>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 106: return fwd_ab_all_channels<0, 3>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 107: return fwd_ab_all_channels<2, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 111: return fwd_asm_all_channels<false, 0, 8, 2>(input, vertical, horizontal, output, B, C, H, W, s);
         case 112: return fwd_asm_all_channels<false, 0, 8, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 103: return fwd_asm_all_channels<false, 3, 8>(input, vertical, horizontal, output, B, C, H, W, s);
@@ -269,7 +271,8 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 105: return fwd_asm_all_channels<false, 3, 4>(input, vertical, horizontal, output, B, C, H, W, s);
         case 101: return fwd_asm_all_channels<false, 1>(input, vertical, horizontal, output, B, C, H, W, s);
         case 102: return fwd_asm_all_channels<false, 2>(input, vertical, horizontal, output, B, C, H, W, s);
-        default: return fail(TAI_SEPCONV_EINVAL, "%s", "unknown forward variant");
+#endif
+        default: return fail(TAI_SEPCONV_EINVAL, "%s", "unknown forward variant (values >= 100 exist only in the tools build, -DTAI_TIMING_VARIANTS)");
     }
 }
 
@@ -385,10 +388,18 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
 static int wino_forward_impl(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C,
                              int K, int H, int W, int act, void* hip_stream, long long* stamps, float* ypool = nullptr,
                              int in_h = 0, int in_w = 0, int in_oy = 0, int in_ox = 0);
-static int g_wino_tall = 1;            // 1: use the 128 x 32 workgroup shape when K is a multiple of 128
-int tai_conv3x3_wino_set_tall(int on) { const int prev = g_wino_tall; g_wino_tall = on ? 1 : 0; return prev; }
-static int g_wino_timeline_skip = 0;   // timeline launches only: loop parts left out (wino_conv.hip.inc, SKIP)
-int tai_conv3x3_wino_timeline_skip(int level) { g_wino_timeline_skip = level; return 0; }
+static std::atomic<int> g_wino_tall{1};            // 1: use the 128 x 32 workgroup shape when K is a multiple of 128
+int tai_conv3x3_wino_set_tall(int on) { return g_wino_tall.exchange(on ? 1 : 0, std::memory_order_relaxed); }
+static std::atomic<int> g_wino_timeline_skip{0};   // timeline launches only: loop parts left out (wino_conv.hip.inc, SKIP)
+int tai_conv3x3_wino_timeline_skip(int level) {
+#ifdef TAI_TIMING_VARIANTS
+    g_wino_timeline_skip.store(level, std::memory_order_relaxed);
+    return 0;
+#else
+    if (level == 0) return 0;
+    return fail(TAI_SEPCONV_EINVAL, "%s", "timeline skip levels exist only in the tools build (-DTAI_TIMING_VARIANTS)");
+#endif
+}
 
 int tai_conv3x3_wino_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W,
                              int act, void* hip_stream) {
@@ -447,7 +458,9 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
     const long long tiles = (long long)N * (H / 2) * (W / 2);
     const long long tblocks = (tiles + wino::TN - 1) / wino::TN;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    const bool tall = Kpad % wino::TTM == 0 && g_wino_tall != 0;
+    const bool tall = Kpad % wino::TTM == 0 && g_wino_tall.load(std::memory_order_relaxed) != 0;
+    const int skip = g_wino_timeline_skip.load(std::memory_order_relaxed);
+    (void)skip;
 #define TAI_LAUNCH_WINO(A, D, ...)                                                                                     \
     do {                                                                                                               \
         if (int rc = allow_lds(wino::conv3x3<A, D, ##__VA_ARGS__>, wino::LDS_BYTES)) return rc;                          \
@@ -465,21 +478,26 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
                            xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, Kpad, \
                            nchunks, tkb, stamps);                                                                      \
     } while (0)
-        if (stamps && g_wino_timeline_skip == 1) TAI_LAUNCH_WINO_TALL(1, 0, 1, 1);
-        else if (stamps && g_wino_timeline_skip == 2) TAI_LAUNCH_WINO_TALL(1, 0, 1, 2);
-        else if (stamps && g_wino_timeline_skip == 4) TAI_LAUNCH_WINO_TALL(1, 0, 1, 4);
-        else if (stamps && g_wino_timeline_skip == 5) TAI_LAUNCH_WINO_TALL(1, 0, 1, 5);
-        else if (stamps && g_wino_timeline_skip == 7) TAI_LAUNCH_WINO_TALL(1, 0, 2, 0);
-        else if (stamps) TAI_LAUNCH_WINO_TALL(1, 0, 1, 0);
+#ifdef TAI_TIMING_VARIANTS
+        if (stamps && skip == 1) TAI_LAUNCH_WINO_TALL(1, 0, 1, 1);
+        else if (stamps && skip == 2) TAI_LAUNCH_WINO_TALL(1, 0, 1, 2);
+        else if (stamps && skip == 4) TAI_LAUNCH_WINO_TALL(1, 0, 1, 4);
+        else if (stamps && skip == 5) TAI_LAUNCH_WINO_TALL(1, 0, 1, 5);
+        else if (stamps && skip == 7) TAI_LAUNCH_WINO_TALL(1, 0, 2, 0);
+        else
+#endif
+        if (stamps) TAI_LAUNCH_WINO_TALL(1, 0, 1, 0);
         else if (nparts > 1) { if (act == 0) TAI_LAUNCH_WINO_TALL(0, 1, 0, 0, 1); else if (act == 1) TAI_LAUNCH_WINO_TALL(1, 1, 0, 0, 1); else TAI_LAUNCH_WINO_TALL(2, 1, 0, 0, 1); }
         else { if (act == 0) TAI_LAUNCH_WINO_TALL(0, 0, 0, 0, 0); else if (act == 1) TAI_LAUNCH_WINO_TALL(1, 0, 0, 0, 0); else TAI_LAUNCH_WINO_TALL(2, 0, 0, 0, 0); }
 #undef TAI_LAUNCH_WINO_TALL
     }
-    else if (stamps && g_wino_timeline_skip == 1) TAI_LAUNCH_WINO(1, 1, 1);
-    else if (stamps && g_wino_timeline_skip == 2) TAI_LAUNCH_WINO(1, 1, 2);
-    else if (stamps && g_wino_timeline_skip == 4) TAI_LAUNCH_WINO(1, 1, 4);
-    else if (stamps && g_wino_timeline_skip == 7) TAI_LAUNCH_WINO(1, 2, 0);
-    else if (stamps && g_wino_timeline_skip == 5) TAI_LAUNCH_WINO(1, 1, 5);
+#ifdef TAI_TIMING_VARIANTS
+    else if (stamps && skip == 1) TAI_LAUNCH_WINO(1, 1, 1);
+    else if (stamps && skip == 2) TAI_LAUNCH_WINO(1, 1, 2);
+    else if (stamps && skip == 4) TAI_LAUNCH_WINO(1, 1, 4);
+    else if (stamps && skip == 7) TAI_LAUNCH_WINO(1, 2, 0);
+    else if (stamps && skip == 5) TAI_LAUNCH_WINO(1, 1, 5);
+#endif
     else if (stamps) TAI_LAUNCH_WINO(1, 1);
     else if (nparts > 1 && act == 0) TAI_LAUNCH_WINO(0, 0, 0, 1);
     else if (nparts > 1 && act == 1) TAI_LAUNCH_WINO(1, 0, 0, 1);
@@ -523,7 +541,7 @@ int tai_sepconv_backward(const float* grad_output, const float* input, const flo
 
     // gV then gH then gI: the reference's launch order (SeparableConvolution_kernel.cu:201-239).
     const bool tileable = (ks == 51) && (W % 4 == 0) && (C == 1 || C == 3);
-    if (tileable && C == 1 && grad_vertical && grad_horizontal && g_vh_variant != 1) {
+    if (tileable && C == 1 && grad_vertical && grad_horizontal && g_vh_variant.load(std::memory_order_relaxed) != 1) {
         // both tap gradients of a single-channel frame in one launch of the hand-scheduled wave types
         const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W, tiles_y = (H + 7) / 8;
         const size_t patch = (size_t)(8 + 50) * 180 * sizeof(float);
@@ -553,7 +571,7 @@ int tai_sepconv_backward(const float* grad_output, const float* input, const flo
         }
     }
     if (grad_input) {
-        if (tileable && g_gi_variant != 1) {
+        if (tileable && g_gi_variant.load(std::memory_order_relaxed) != 1) {
             // LDS row-scatter (C == 1 or 3 here): the kernel accumulates into gI with atomics, so zero it first
             const size_t bytes = (size_t)B * C * (H + ks - 1) * (W + ks - 1) * sizeof(float);
             if (hipMemsetAsync(grad_input, 0, bytes, s) != hipSuccess) return fail(TAI_SEPCONV_ELAUNCH, "%s", "hipMemsetAsync(gI)");

@@ -20,7 +20,7 @@ import os
 import numpy as np
 import torch
 
-from . import parallel
+from . import conv_ops, parallel
 from .graph import GraphedForward
 from .losses import GDL
 from .mcnet import MCNetFillInModel
@@ -104,6 +104,7 @@ class BaseVideoFillInEnvironment(object):
         else:
             raise RuntimeError('Failed to find snapshot at path %s' % save_path)
         self.generator.load_state_dict(snapshot['generator'])
+        conv_ops.invalidate_derived(self.generator)
         self._graphs.clear()
         return snapshot
 
@@ -123,7 +124,14 @@ class BaseTrainingEnvironment(BaseVideoFillInEnvironment):
         self.max_K, self.max_T, self.max_F = max_K, max_T, max_F
         self.optimizer_G = torch.optim.Adam(self.generator.parameters(), lr=lr, betas=(beta1, 0.999))
         self._reducer_G = parallel.GradAllReducer(self.generator.parameters())
-        self._ktf_rng = np.random       # global numpy RNG as in the reference; seed it identically on every rank
+        # The reference draws (K, T, F) from the global numpy RNG (environments.py:417-427).  Data-parallel replicas must
+        # draw the SAME values every step, and anything else that touches the global RNG on one rank only (a data-loader
+        # retry, user code) would make them diverge for the rest of the run: a private stream, seeded identically on
+        # every rank (``seed_KTF`` to change it).
+        self._ktf_rng = np.random.RandomState(0)
+
+    def seed_KTF(self, seed):
+        self._ktf_rng = np.random.RandomState(seed)
 
     def sample_KTF(self, allow_random_sampling):
         if allow_random_sampling:

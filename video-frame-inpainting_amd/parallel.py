@@ -58,8 +58,10 @@ def broadcast_module_state(module, src=0):
     """Make every replica's parameters AND buffers (persistent or not, e.g. the SN ``u`` vectors) equal to rank src's."""
     if world_size() == 1:
         return
+    from . import conv_ops
     for t in list(module.parameters()) + [b for b in module.buffers() if b is not None]:
-        dist.broadcast(t.data, src=src)
+        dist.broadcast(t.detach(), src=src)        # detach() shares the version counter with t; .data would not
+    conv_ops.invalidate_derived(module)            # belt and braces: derived weights are rebuilt from the received ones
 
 
 def materialise_sn_vectors(discriminator):

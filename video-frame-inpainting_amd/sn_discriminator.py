@@ -37,11 +37,18 @@ class _SpectralNormalised(object):
         self.register_buffer('u', None, persistent=False)
 
     def _renormalise_(self):
+        """Renormalises the parameter in place and returns the weight to convolve with.  Under torch 0.3.1 autograd kept
+        the weight TENSOR of the moment for the backward pass, so each window back-propagates through the weights it
+        was evaluated with, although 12 later windows (and later forwards) have rescaled the parameter since.  Modern
+        autograd keeps a leaf parameter by reference and would back-propagate through the LATEST ``.data``; the
+        returned ``weight + 0`` is a value of the moment with its own storage whose gradient still accumulates in the
+        parameter, which restores the reference's behaviour."""
         w_mat = self.weight.view(self.weight.size(0), -1)
         sigma, u = max_singular_value(w_mat, self.u, Ip=self.Ip)
         self.u = u
         with torch.no_grad():
             self.weight.data = self.weight.data / sigma     # in place, cumulative: SNDiscriminator.py:67,91
+        return self.weight + 0 if torch.is_grad_enabled() and self.weight.requires_grad else self.weight
 
 
 class SNConv2d(nn.Conv2d, _SpectralNormalised):
@@ -50,8 +57,7 @@ class SNConv2d(nn.Conv2d, _SpectralNormalised):
         self._init_sn(Ip)
 
     def forward(self, input):
-        self._renormalise_()
-        return F.conv2d(input, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        return F.conv2d(input, self._renormalise_(), self.bias, self.stride, self.padding, self.dilation, self.groups)
 
 
 class SNLinear(nn.Linear, _SpectralNormalised):
@@ -60,8 +66,7 @@ class SNLinear(nn.Linear, _SpectralNormalised):
         self._init_sn(Ip)
 
     def forward(self, input):
-        self._renormalise_()
-        return F.linear(input, self.weight, self.bias)
+        return F.linear(input, self._renormalise_(), self.bias)
 
 
 class SNDiscriminator(nn.Module):

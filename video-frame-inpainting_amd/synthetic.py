@@ -38,3 +38,23 @@ def make_clips(B, n_frames, C, H, W, seed):
 def split_clip(clips, K, T, F):
     """-> (preceding [:, :K], middle ground truth [:, K:K+T], following [:, K+T:K+T+F])  (predict.py:49-50, train.py:111-114)."""
     return clips[:, :K], clips[:, K:K + T], clips[:, K + T:K + T + F]
+
+
+def seeded_init(module, seed, bias_std=0.1):
+    """Deterministic non-trivial weights AND biases for parity checks and benchmarks (there is no network for the
+    published checkpoints): weights ~ N(0, 1/fan_in), biases ~ N(0, bias_std^2), drawn from a private CPU generator in
+    sorted parameter-name order, so the result does not depend on the device or on construction order.  The
+    reference's own init (util.py:193-196: xavier-normal weights, ZERO biases) makes the kernel network emit taps of
+    ~1e-4 and every prediction a constant gray frame -- useless as parity evidence; with these weights the 51 taps per
+    pixel are O(0.1) and the predictions span the gray range.  Writes through ``copy_`` under ``no_grad`` so the
+    tensors' version counters move (conv_ops caches derived weights per version)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for _, p in sorted(module.named_parameters()):
+            if p.dim() > 1:
+                std = 1.0 / np.sqrt(max(p[0].numel(), 1))
+            else:
+                std = bias_std
+            p.copy_((torch.randn(p.shape, generator=g) * std).to(p.device))
+    return module

@@ -44,13 +44,16 @@ def weights_init(m):
     """Xavier-normal (gain 1) conv / conv-transpose weights with zero bias; U(0, 0.02) linear weights
     (util.py:193-199).  Spectral-norm layers are handled by their own classes' ``reset``."""
     from .sn_discriminator import SNConv2d, SNLinear
-    if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, SNConv2d)):
-        init.xavier_normal_(m.weight.data, gain=1)
-        if m.bias is not None:
-            init.constant_(m.bias.data, 0.0)
-    elif isinstance(m, (nn.Linear, SNLinear)):
-        init.uniform_(m.weight.data, 0.0, 0.02)
-        init.constant_(m.bias.data, 0.0)
+    # written through the parameters themselves (not ``.data``) under no_grad, so their version counters move and
+    # conv_ops rebuilds the derived (Winograd-domain / flipped) weights it caches per version
+    with torch.no_grad():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, SNConv2d)):
+            init.xavier_normal_(m.weight, gain=1)
+            if m.bias is not None:
+                init.constant_(m.bias, 0.0)
+        elif isinstance(m, (nn.Linear, SNLinear)):
+            init.uniform_(m.weight, 0.0, 0.02)
+            init.constant_(m.bias, 0.0)
 
 
 def move_to_devices(model, device=None):
