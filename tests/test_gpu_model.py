@@ -46,7 +46,7 @@ def test_matches_reference_golden_run(golden_dir, tag):
 REL_TOL = 1e-4      # per output key: max |gpu - oracle| <= REL_TOL * max |oracle|  (fp32, different summation orders)
 
 
-def _assert_matches_oracle(out, ref, GT, name=''):
+def _assert_matches_oracle(out, ref, GT, name='', min_levels=50, min_spread=0.05):
     """Outputs within REL_TOL of the oracle relative to each key's own magnitude, AND the comparison is about something:
     the uint8 prediction spans many gray levels, PSNR vs ground truth differs between frames, and PSNR / SSIM vs ground
     truth agree between GPU and oracle (0.01 dB / 1e-4)."""
@@ -56,11 +56,11 @@ def _assert_matches_oracle(out, ref, GT, name=''):
         err = float((out[k].cpu() - ref[k]).abs().max())
         assert err <= REL_TOL * scale, (name, k, err, scale)
     pred_gpu, pred_cpu = out['pred'].cpu().numpy(), ref['pred'].numpy()
-    assert len(np.unique(metrics.to_uint8(pred_gpu))) > 50, name
+    assert len(np.unique(metrics.to_uint8(pred_gpu))) > min_levels, name
     p_gpu, s_gpu, _ = metrics.compute_errors(pred_gpu, GT.numpy())
     p_cpu, s_cpu, _ = metrics.compute_errors(pred_cpu, GT.numpy())
     if p_cpu.size > 1:
-        assert p_cpu.max() - p_cpu.min() > 0.05, (name, p_cpu)       # frames differ: the deltas below carry information
+        assert p_cpu.max() - p_cpu.min() > min_spread, (name, p_cpu)       # frames differ: the deltas below carry information
     assert np.max(np.abs(p_gpu - p_cpu)) <= 0.01, (name, p_gpu, p_cpu)     # dB
     assert np.max(np.abs(s_gpu - s_cpu)) <= 1e-4, (name, s_gpu, s_cpu)
 
@@ -241,7 +241,9 @@ def test_other_baseline_config_shapes_match_cpu_oracle(name, c_dim, num_block, H
         out = m.to(DEV).eval()(T, P.to(DEV), Fo.to(DEV))
     for k in KEYS:
         assert out[k].shape == ref[k].shape == (1, T, c_dim, H, W)
-    _assert_matches_oracle(out, ref, GT, name)
+    # width 8 gives a narrower output range than the real model, and the 4-block colour model never sees the time ratio
+    # (tai.py:213-217), so its frames differ less
+    _assert_matches_oracle(out, ref, GT, name, min_levels=30, min_spread=0.01)
 
 
 def test_predict_and_train_drivers_run_end_to_end(tmp_path, monkeypatch):
