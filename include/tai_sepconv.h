@@ -150,9 +150,15 @@ int tai_sepconv_set_forward_variant(int variant);
 /* The variant `0 = automatic` resolves to for a frame of C channels, width W and filter size ks. */
 int tai_sepconv_default_forward_variant(int C, int W, int ks);
 
-/* grad_input kernel of tai_sepconv_backward: 0 = automatic (LDS row-scatter when ks == 51, W % 4 == 0, C in {1, 3};
- * accumulates with float atomics: last bits depend on arrival order), 1 = bounds-checked gather (any shape, bit-
- * reproducible, ~40x slower).  Returns the previous value. */
+/* grad_input kernel of tai_sepconv_backward:
+ *   0 = automatic: wave-private accumulation strips + fixed-order slab sum when ks == 51, W % 4 == 0, C in {1, 3} --
+ *       bit-reproducible; the tile slabs borrow the caller's grad_vertical (or grad_horizontal) buffer before that gradient
+ *       is written, so gI is computed FIRST (with neither buffer given, the strips flush with float atomics instead);
+ *       any other shape: the bounds-checked gather;
+ *   1 = bounds-checked gather of the reference (any shape, bit-reproducible, ~40x slower);
+ *   2 = round-1 kernel: LDS row-scatter with a barrier per tap row and float atomics (last bits depend on arrival order);
+ *   3 = as 0 (explicit).
+ * Returns the previous value. */
 int tai_sepconv_set_grad_input_variant(int variant);
 
 /* grad_vertical / grad_horizontal kernels: 0 = automatic (one fused launch of the hand-scheduled wave types when C == 1

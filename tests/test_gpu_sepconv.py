@@ -130,23 +130,54 @@ def test_adjoint_identity_at_full_size():
             assert abs(lhs - rhs) <= 1e-4 * (1 + abs(lhs)), (lhs, rhs)
 
 
-def test_both_grad_input_kernels_match_oracle():
-    # LDS row-scatter (default when tileable) and the reference-style gather must agree with the oracle and each other
-    inp, v, h, gO = _case(2, 3, 20, 132, 51, 12)
-    _, _, _ = None, None, None
-    rI, _, _ = so.backward(gO.numpy(), inp.numpy(), v.numpy(), h.numpy(), 51, f64=True)
+def _grad_input(inp, v, h, gO, variant, taps_too=True):
     L = _native.lib()
-    got = []
-    for variant in (0, 1):
-        prev = L.tai_sepconv_set_grad_input_variant(variant)
-        try:
-            di = inp.to(DEV).requires_grad_()
-            vfi.SeparableConvolution.apply(di, v.to(DEV), h.to(DEV), 51).backward(gO.to(DEV))
-            got.append(di.grad.cpu().numpy())
-        finally:
-            L.tai_sepconv_set_grad_input_variant(prev)
-        assert _rel(got[-1], rI) < BWD_TOL
-    assert _rel(got[0], got[1].astype(np.float64)) < BWD_TOL
+    prev = L.tai_sepconv_set_grad_input_variant(variant)
+    try:
+        di = inp.to(DEV).requires_grad_()
+        dv, dh = v.to(DEV), h.to(DEV)
+        if taps_too:
+            dv.requires_grad_(); dh.requires_grad_()
+        vfi.SeparableConvolution.apply(di, dv, dh, 51).backward(gO.to(DEV))
+        return di.grad.clone()
+    finally:
+        L.tai_sepconv_set_grad_input_variant(prev)
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 3, 20, 132), (2, 1, 33, 128), (1, 1, 128, 128), (1, 3, 7, 260)])
+def test_all_grad_input_kernels_match_oracle(B, C, H, W):
+    # 0 / 3: wave-private strips + fixed-order slab sum (default when tileable); 1: the reference-style gather; 2: the
+    # round-1 LDS row-scatter with atomics.  All against the fp64 oracle, and against each other.
+    inp, v, h, gO = _case(B, C, H, W, 51, 12)
+    rI, _, _ = so.backward(gO.numpy(), inp.numpy(), v.numpy(), h.numpy(), 51, f64=True)
+    got = {}
+    for variant in (0, 1, 2, 3):
+        got[variant] = _grad_input(inp, v, h, gO, variant).cpu().numpy()
+        assert _rel(got[variant], rI) < BWD_TOL, variant
+    assert np.array_equal(got[0], got[3])
+    # with no tap gradient requested there is no buffer to borrow for the tile slabs: the strips flush with atomics
+    alone = _grad_input(inp, v, h, gO, 0, taps_too=False).cpu().numpy()
+    assert _rel(alone, rI) < BWD_TOL
+
+
+def test_default_grad_input_is_bit_reproducible():
+    inp, v, h, gO = _case(4, 1, 64, 128, 51, 14)
+    a = _grad_input(inp, v, h, gO, 0)
+    for _ in range(3):
+        assert torch.equal(a, _grad_input(inp, v, h, gO, 0))
+
+
+def test_grad_input_of_delta_taps_is_an_exact_scatter():
+    # v = e_i, h = e_j: out[y, x] = in[y+i, x+j], so gI[y+i, x+j] = gO[y, x] and zero elsewhere -- exactly
+    B, C, H, W, ks, i, j = 2, 1, 24, 128, 51, 7, 40
+    g = torch.Generator().manual_seed(15)
+    inp = torch.randn(B, C, H + ks - 1, W + ks - 1, generator=g)
+    gO = torch.randn(B, C, H, W, generator=g)
+    v = torch.zeros(B, ks, H, W); v[:, i] = 1
+    h = torch.zeros(B, ks, H, W); h[:, j] = 1
+    want = torch.zeros_like(inp)
+    want[:, :, i:i + H, j:j + W] = gO
+    assert torch.equal(_grad_input(inp, v, h, gO, 0).cpu(), want)
 
 
 def test_fused_and_separate_tap_gradient_kernels_agree():

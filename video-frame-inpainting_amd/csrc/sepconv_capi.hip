@@ -539,8 +539,43 @@ int tai_sepconv_backward(const float* grad_output, const float* input, const flo
     if (!dims_ok(B, C, H, W, ks)) return fail(TAI_SEPCONV_EINVAL, "%s", "bad dimensions");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
 
-    // gV then gH then gI: the reference's launch order (SeparableConvolution_kernel.cu:201-239).
     const bool tileable = (ks == 51) && (W % 4 == 0) && (C == 1 || C == 3);
+    const int gi_variant = g_gi_variant.load(std::memory_order_relaxed);
+    bool gi_done = false;
+    if (grad_input && tileable && (gi_variant == 0 || gi_variant == 3)) {
+        // gI FIRST (the reference launches V, H, I -- SeparableConvolution_kernel.cu:201-239 -- but the three are
+        // independent): wave-private accumulation strips; the tile slabs go to the caller's grad_vertical (or
+        // grad_horizontal) buffer, which is filled only afterwards, and a second kernel sums them in a fixed order.
+        const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W, tiles_y = (H + bwd::gi2::R - 1) / bwd::gi2::R;
+        const long long slab_bytes = (long long)B * tiles_x * tiles_y * C * bwd::gi2::SLAB * (long long)sizeof(float);
+        float* scratch = grad_vertical ? grad_vertical : grad_horizontal;
+        if (slab_bytes > (long long)B * ks * H * W * (long long)sizeof(float)) scratch = nullptr;   // cannot happen for ks = 51
+        const size_t lds = (size_t)bwd::gi2::LDS_FLOATS * sizeof(float);
+        const dim3 grid(B * tiles_x * tiles_y), block(512);
+        float* dst = scratch ? scratch : grad_input;
+        if (!scratch) {      // no buffer to borrow: float atomics on a zeroed gI (last bits then depend on arrival order)
+            const size_t bytes = (size_t)B * C * (H + ks - 1) * (W + ks - 1) * sizeof(float);
+            if (hipMemsetAsync(grad_input, 0, bytes, s) != hipSuccess) return fail(TAI_SEPCONV_ELAUNCH, "%s", "hipMemsetAsync(gI)");
+        }
+        if (C == 1) {
+            auto kern = bwd::sepconv_grad_i_strips<1>;
+            if (int rc = allow_lds(kern, lds)) return rc;
+            hipLaunchKernelGGL(kern, grid, block, lds, s, grad_output, vertical, horizontal, dst, H, W, tiles_x, tiles_y, scratch ? 1 : 0);
+        } else {
+            auto kern = bwd::sepconv_grad_i_strips<3>;
+            if (int rc = allow_lds(kern, lds)) return rc;
+            hipLaunchKernelGGL(kern, grid, block, lds, s, grad_output, vertical, horizontal, dst, H, W, tiles_x, tiles_y, scratch ? 1 : 0);
+        }
+        if (int rc = check_launch("sepconv_grad_i_strips")) return rc;
+        if (scratch) {
+            const int n = B * C * (H + ks - 1) * ((W + ks - 1) / 2);
+            hipLaunchKernelGGL(bwd::sepconv_grad_i_reduce, dim3((n + 255) / 256), dim3(256), 0, s, scratch, grad_input, n, C, H, W,
+                               tiles_x, tiles_y);
+            if (int rc = check_launch("sepconv_grad_i_reduce")) return rc;
+        }
+        gi_done = true;
+    }
+
     if (tileable && C == 1 && grad_vertical && grad_horizontal && g_vh_variant.load(std::memory_order_relaxed) != 1) {
         // both tap gradients of a single-channel frame in one launch of the hand-scheduled wave types
         const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W, tiles_y = (H + 7) / 8;
@@ -570,9 +605,9 @@ int tai_sepconv_backward(const float* grad_output, const float* input, const flo
             if (int rc = check_launch("sepconv_grad_h_generic")) return rc;
         }
     }
-    if (grad_input) {
-        if (tileable && g_gi_variant.load(std::memory_order_relaxed) != 1) {
-            // LDS row-scatter (C == 1 or 3 here): the kernel accumulates into gI with atomics, so zero it first
+    if (grad_input && !gi_done) {
+        if (tileable && gi_variant == 2) {
+            // first form: LDS row-scatter with a barrier per tap row; accumulates into gI with atomics, so zero it first
             const size_t bytes = (size_t)B * C * (H + ks - 1) * (W + ks - 1) * sizeof(float);
             if (hipMemsetAsync(grad_input, 0, bytes, s) != hipSuccess) return fail(TAI_SEPCONV_ELAUNCH, "%s", "hipMemsetAsync(gI)");
             const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W, tiles_y = (H + 7) / 8;
