@@ -70,6 +70,12 @@ int tai_bias_act_inplace(float* x, const float* bias, int N, int C, int HW, int 
  * src/models/mcnet/mcnet.py:234-236, 240-256); fp32 contiguous, w even; out may not alias x or res. */
 int tai_unpool2x_add(const float* x, const float* res, float* out, long long planes, int h, int w, void* hip_stream);
 
+/* ConvLSTM gate arithmetic in one pass (ConvLstmCell.forward, src/models/mcnet/mcnet.py:287-293): gates [N, 4F, HW] holds the
+ * chunks (i, j, f, o) of conv(cat(input, h)); c, new_c, new_h are [N, F, HW]; HW % 4 == 0.
+ *   new_c = c * sigmoid(f + forget_bias) + sigmoid(i) * tanh(j);   new_h = tanh(new_c) * sigmoid(o). */
+int tai_convlstm_gates_forward(const float* gates, const float* c, float* new_c, float* new_h, int N, int F, int HW,
+                               float forget_bias, void* hip_stream);
+
 /* Direct "same"-padded stride-1 convolutions for the generator's thin layers, bias and activation fused (act: 0 none,
  * 1 ReLU, 2 tanh), fp32 NCHW contiguous, W % 4 == 0:
  *   tai_conv_cin1_forward       x [N,1,H,W], weight [Co,1,k,k] (k in {3,5}), y [N,Co,H,W]   (nn.Conv2d(1, gf, 5, padding=2)

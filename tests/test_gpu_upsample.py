@@ -8,18 +8,22 @@ from video_frame_inpainting_amd.upsample import upsample2x
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('shape', [(2, 3, 5, 6), (1, 1, 1, 2), (2, 51, 64, 64), (1, 65, 16, 16), (3, 2, 7, 1), (1, 4, 4, 3)])
+@pytest.mark.parametrize('shape', [(2, 3, 5, 6), (1, 1, 1, 2), (2, 51, 64, 64), (1, 65, 16, 16), (3, 2, 7, 1), (1, 4, 4, 3), (70000, 1, 2, 2), (1, 3, 32, 48)])
 def test_matches_aten(shape):
     x = torch.randn(*shape, generator=torch.Generator().manual_seed(1))
     want = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
     exact = F.interpolate(x.double(), scale_factor=2, mode='bilinear', align_corners=True)
     got = upsample2x(x.cuda())
     assert got.shape == want.shape
-    # against the exact (fp64) interpolation: fp32 rounding of the source coordinate and of the 2x2 blend
-    assert float((got.cpu().double() - exact).abs().max()) <= 5e-6
-    # ATen's fp32 kernels (CPU and GPU agree bit for bit) sit 1.4e-5 from the exact result at 64 -> 128 (measured on
-    # MI355X, tools/up_probe.py); this kernel is 2.4e-6 from it, so the two differ by up to ~1.4e-5
-    assert float((got.cpu() - want).abs().max()) <= 5e-5
+    # against the exact (fp64) interpolation: fp32 rounding of the source coordinate and of the 2x2 blend (ATen's own
+    # fp32 kernels sit 1.4e-5 from it at 64 -> 128)
+    assert float((got.cpu().double() - exact).abs().max()) <= 2e-5
+    # ATen's fp32 kernels are the CPU oracle's arithmetic.  The two-rows-per-thread kernel (every shape with H, W >= 2)
+    # evaluates the same expression: bit-identical at the production shape (64 -> 128), within an ulp or two elsewhere
+    # (the compilers contract the blend differently); the fall-back kernels within 5e-5.
+    if shape == (2, 51, 64, 64):
+        assert torch.equal(got.cpu(), want)
+    assert float((got.cpu() - want).abs().max()) <= (2e-6 if shape[2] >= 2 and shape[3] >= 2 else 5e-5)
 
 
 def test_backward_matches_aten():

@@ -304,7 +304,8 @@ int tai_conv_cin1_forward(const float* x, const float* weight, const float* bias
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const long long work = (long long)N * H * (W / 4);
     const int blocks = (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192);
-#define TAI_LAUNCH_CIN1(K, A) hipLaunchKernelGGL((thin::conv_cin1<K, A>), dim3(blocks), dim3(256), 0, s, x, weight, bias, y, N, Co, H, W)
+    const int cgroups = (work < 4 * 262144 && Co >= 16) ? 4 : 1;      // few waves: split the output channels over gridDim.y
+#define TAI_LAUNCH_CIN1(K, A) hipLaunchKernelGGL((thin::conv_cin1<K, A>), dim3(blocks, cgroups), dim3(256), 0, s, x, weight, bias, y, N, Co, H, W)
     if (k == 3 && act == 0) TAI_LAUNCH_CIN1(3, 0);
     else if (k == 3) TAI_LAUNCH_CIN1(3, 1);
     else if (act == 0) TAI_LAUNCH_CIN1(5, 0);
@@ -322,7 +323,8 @@ int tai_conv_cin1_forward_maxpool(const float* x, const float* weight, const flo
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const long long work = (long long)N * (H / 2) * (W / 4);
     const int blocks = (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192);
-#define TAI_LAUNCH_CIN1P(K, A) hipLaunchKernelGGL((thin::conv_cin1_pool<K, A>), dim3(blocks), dim3(256), 0, s, x, weight, bias, y, ypool, N, Co, H, W)
+    const int cgroups = (work < 4 * 262144 && Co >= 16) ? 4 : 1;
+#define TAI_LAUNCH_CIN1P(K, A) hipLaunchKernelGGL((thin::conv_cin1_pool<K, A>), dim3(blocks, cgroups), dim3(256), 0, s, x, weight, bias, y, ypool, N, Co, H, W)
     if (k == 3 && act == 0) TAI_LAUNCH_CIN1P(3, 0);
     else if (k == 3) TAI_LAUNCH_CIN1P(3, 1);
     else if (act == 0) TAI_LAUNCH_CIN1P(5, 0);
@@ -339,6 +341,18 @@ int tai_unpool2x_add(const float* x, const float* res, float* out, long long pla
     const int blocks = (int)((work + 255) / 256 < 16384 ? (work + 255) / 256 : 16384);
     hipLaunchKernelGGL(bact::unpool2x_add, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), x, res, out, planes, h, w);
     return check_launch("unpool2x_add");
+}
+
+int tai_convlstm_gates_forward(const float* gates, const float* c, float* new_c, float* new_h, int N, int F, int HW,
+                               float forget_bias, void* hip_stream) {
+    g_err[0] = 0;
+    if (!gates || !c || !new_c || !new_h) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (N <= 0 || F <= 0 || HW <= 0 || HW % 4 != 0) return fail(TAI_SEPCONV_EINVAL, "%s", "convlstm_gates: needs HW % 4 == 0");
+    const long long work = (long long)N * F * (HW / 4);
+    const int blocks = (int)((work + 255) / 256 < 16384 ? (work + 255) / 256 : 16384);
+    hipLaunchKernelGGL(bact::convlstm_gates, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), gates, c, new_c,
+                       new_h, N, F, HW / 4, forget_bias);
+    return check_launch("convlstm_gates");
 }
 
 int tai_conv_shift_stack(const float* x, float* out, int N, int C, int H, int W, int k, void* hip_stream) {
@@ -518,7 +532,13 @@ int tai_upsample_bilinear2x_forward(const float* input, float* output, int plane
     const float rh = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
     const float rw = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
     const long long total = (long long)planes * 2 * H * (2 * W);
-    if ((2 * W) % 4 == 0) {
+    if ((2 * W) % 4 == 0 && H >= 2 && W >= 2 && (long long)H * W * 4 < (1LL << 30)) {
+        // two output rows x four columns per thread from a 3 x 4 source window
+        const int per_plane = H * (2 * W / 4);
+        const int bx = (per_plane + 255) / 256 < 64 ? (per_plane + 255) / 256 : 64;
+        hipLaunchKernelGGL(ups::upsample2x_align_corners_pairs, dim3(bx, planes < 65535 ? planes : 65535), dim3(256), 0, s, input, output, planes, H, W,
+                           rh, rw);
+    } else if ((2 * W) % 4 == 0) {
         const long long threads = total / 4;
         const int blocks = (int)((threads + 255) / 256 < 65536 ? (threads + 255) / 256 : 65536);
         hipLaunchKernelGGL(ups::upsample2x_align_corners_quads, dim3(blocks), dim3(256), 0, s, input, output, planes, H,

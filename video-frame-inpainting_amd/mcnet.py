@@ -173,12 +173,29 @@ class ConvLstmCell(nn.Module):
         self.conv = nn.Conv2d(num_features * 2, num_features * 4, feature_size, padding=(feature_size - 1) // 2, bias=bias)
 
     def forward(self, input, state):
-        c, h = torch.chunk(state, 2, dim=1)
-        gates = conv_bias_act(torch.cat((input, h), dim=1), self.conv.weight, self.conv.bias, self.conv.padding[0], None)
-        i, j, f, o = torch.chunk(gates, 4, dim=1)
-        new_c = c * torch.sigmoid(f + self.forget_bias) + torch.sigmoid(i) * torch.tanh(j)
-        new_h = torch.tanh(new_c) * torch.sigmoid(o)
-        return new_h, torch.cat((new_c, new_h), dim=1)
+        """``state`` is the reference's cat(c, h) tensor or a (c, h) pair; returns (new_h, state) with ``state`` in the
+        form it came in.  MCNet.forward keeps the pair: no cat / chunk copies, and conv(cat(input, h)) reads its two
+        operands in place."""
+        as_pair = isinstance(state, (tuple, list))
+        c, h = state if as_pair else torch.chunk(state, 2, dim=1)
+        x = (input, h) if (as_pair or h.is_contiguous()) else torch.cat((input, h), dim=1)
+        gates = conv_bias_act(x, self.conv.weight, self.conv.bias, self.conv.padding[0], None)
+        N, F4, H, W = gates.shape
+        fused = (gates.is_cuda and gates.dtype == torch.float32 and (H * W) % 4 == 0 and c.dtype == torch.float32
+                 and not (torch.is_grad_enabled() and (gates.requires_grad or c.requires_grad)))
+        if fused:
+            from . import _native
+            gates, c = gates.contiguous(), c.contiguous()
+            new_c, new_h = torch.empty_like(c), torch.empty_like(c)
+            with torch.cuda.device(gates.device):
+                _native.check(_native.lib().tai_convlstm_gates_forward(
+                    gates.data_ptr(), c.data_ptr(), new_c.data_ptr(), new_h.data_ptr(), N, F4 // 4, H * W,
+                    float(self.forget_bias), torch.cuda.current_stream(gates.device).cuda_stream), 'tai_convlstm_gates_forward')
+        else:
+            i, j, f, o = torch.chunk(gates, 4, dim=1)
+            new_c = c * torch.sigmoid(f + self.forget_bias) + torch.sigmoid(i) * torch.tanh(j)
+            new_h = torch.tanh(new_c) * torch.sigmoid(o)
+        return new_h, ((new_c, new_h) if as_pair else torch.cat((new_c, new_h), dim=1))
 
 
 class MCNet(nn.Module):
@@ -206,7 +223,8 @@ class MCNet(nn.Module):
         Returns lists pred[T], dyn[T], cont[T], res[T] = [res1, res2, res3]."""
         assert K >= 2, 'MC-Net needs at least two input frames (one difference frame)'
         diffs = [diff_in[:, t] for t in range(diff_in.shape[1])]
-        state = self.get_initial_conv_lstm_state(xt.shape[0], xt.shape[2:4], xt)
+        state = torch.chunk(self.get_initial_conv_lstm_state(xt.shape[0], xt.shape[2:4], xt), 2, dim=1)
+        state = (state[0].contiguous(), state[1].contiguous())      # (c, h) kept apart: see ConvLstmCell.forward
         h_dyn = res_m = None
         for t in range(K - 1):
             enc_h, res_m = self.motion_enc(diffs[t])
