@@ -30,11 +30,11 @@ def _kernel_bodies(asm, mangled_prefix):
         yield name, asm[i:asm.find('.end_amdhsa_kernel', i)].splitlines()
 
 
-@pytest.mark.parametrize('kernel,dmas', [('7conv3x3', 8), ('12conv3x3_tall', 16)])
+@pytest.mark.parametrize('tall,dmas', [(0, 8), (1, 16)])
 @pytest.mark.parametrize('parts', [0, 1])
-def test_counted_waits_match_the_loads_behind_the_last_dma(device_asm, parts, kernel, dmas):
-    # conv3x3<ACT 1, DBG 0, SKIP 0, PARTS parts> and its 128 x 32 twin: the instantiations the product launches
-    prefix = '_ZN4wino%sILi1ELi0ELi0ELi%dE' % (kernel, parts)
+def test_counted_waits_match_the_loads_behind_the_last_dma(device_asm, parts, tall, dmas):
+    # conv3x3<ACT 1, DBG 0, SKIP 0, PARTS parts, TALL tall> (64 x 64 and 128 x 32 workgroups): the instantiations the product launches
+    prefix = '_ZN4wino7conv3x3ILi1ELi0ELi0ELi%dELb%dE' % (parts, tall)
     found = 0
     for name, lines in _kernel_bodies(device_asm, prefix):
         found += 1

@@ -485,10 +485,10 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
         // 128-channel x 32-tile workgroups (half the patch transform and LDS writes per MFMA) when K allows
         const long long ttb = (tiles + wino::TTN - 1) / wino::TTN;
         const int tkb = Kpad / wino::TTM;
-#define TAI_LAUNCH_WINO_TALL(A, P, ...)                                                                                 \
+#define TAI_LAUNCH_WINO_TALL(A, Q, D, S)                                                                                 \
     do {                                                                                                               \
-        if (int rc = allow_lds(wino::conv3x3_tall<A, ##__VA_ARGS__>, wino::TLDS_BYTES)) return rc;                     \
-        hipLaunchKernelGGL((wino::conv3x3_tall<A, ##__VA_ARGS__>), dim3((unsigned)(ttb * tkb)), dim3(256), wino::TLDS_BYTES, s, \
+        if (int rc = allow_lds(wino::conv3x3<A, D, S, Q, true>, wino::TLDS_BYTES)) return rc;                          \
+        hipLaunchKernelGGL((wino::conv3x3<A, D, S, Q, true>), dim3((unsigned)(ttb * tkb)), dim3(256), wino::TLDS_BYTES, s, \
                            xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, Kpad, \
                            nchunks, tkb, stamps);                                                                      \
     } while (0)
@@ -501,8 +501,8 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
         else
 #endif
         if (stamps) TAI_LAUNCH_WINO_TALL(1, 0, 1, 0);
-        else if (nparts > 1) { if (act == 0) TAI_LAUNCH_WINO_TALL(0, 1, 0, 0, 1); else if (act == 1) TAI_LAUNCH_WINO_TALL(1, 1, 0, 0, 1); else TAI_LAUNCH_WINO_TALL(2, 1, 0, 0, 1); }
-        else { if (act == 0) TAI_LAUNCH_WINO_TALL(0, 0, 0, 0, 0); else if (act == 1) TAI_LAUNCH_WINO_TALL(1, 0, 0, 0, 0); else TAI_LAUNCH_WINO_TALL(2, 0, 0, 0, 0); }
+        else if (nparts > 1) { if (act == 0) TAI_LAUNCH_WINO_TALL(0, 1, 0, 0); else if (act == 1) TAI_LAUNCH_WINO_TALL(1, 1, 0, 0); else TAI_LAUNCH_WINO_TALL(2, 1, 0, 0); }
+        else { if (act == 0) TAI_LAUNCH_WINO_TALL(0, 0, 0, 0); else if (act == 1) TAI_LAUNCH_WINO_TALL(1, 0, 0, 0); else TAI_LAUNCH_WINO_TALL(2, 0, 0, 0); }
 #undef TAI_LAUNCH_WINO_TALL
     }
 #ifdef TAI_TIMING_VARIANTS
