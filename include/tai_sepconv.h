@@ -88,6 +88,11 @@ int tai_conv_cin1_forward(const float* x, const float* weight, const float* bias
 /* tai_conv_cin1_forward that also writes ypool [N,Co,H/2,W/2] = 2x2 max pool of the activated output (even H). */
 int tai_conv_cin1_forward_maxpool(const float* x, const float* weight, const float* bias, float* y, float* ypool, int N, int Co,
                                   int H, int W, int k, int act, void* hip_stream);
+/* ... with ypool written into a plane of pool_h x pool_w whose origin is at (pool_oy, pool_ox):
+ * the halo-carrying input plane of the next layer (tai_conv3x3_wino_forward_ex, shift_s), halo left untouched. */
+int tai_conv_cin1_forward_maxpool_window(const float* x, const float* weight, const float* bias, float* y, float* ypool, int N,
+                                         int Co, int H, int W, int k, int act, int pool_h, int pool_w, int pool_oy, int pool_ox,
+                                         void* hip_stream);
 int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float* bias, float* y, int N, int Ci, int H,
                                int W, int act, void* hip_stream);
 
@@ -125,6 +130,23 @@ int tai_conv3x3_wino_forward_window(const float* x, const float* U, const float*
  * :152, TAI.forward: src/models/tai/tai.py:188).  xs: host array of device pointers; C / nparts must be a multiple of 8. */
 int tai_conv3x3_wino_forward_parts(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N,
                                    int C, int K, int H, int W, int act, void* hip_stream);
+/* The general form of the same convolution (every optional argument may be NULL / 0):
+ *   xs, nparts      1..4 input parts as above; or ONE tensor with shift_s in {2, 3}: the input [N, C / shift_s^2, in_h, in_w]
+ *                   is read shift_s x shift_s times, channel block (a, b) = block a * shift_s + b displaced by (3a, 3b)
+ *                   pixels.  With the k x k weight cut into shift_s x shift_s blocks of 3 x 3 taps ([K, shift_s^2 * Cin, 3, 3],
+ *                   zero past k) this is the k x k "same" convolution of MotionEnc (nn.Conv2d(gf, 2gf, 5, padding=2),
+ *                   nn.Conv2d(2gf, 4gf, 7, padding=3): src/models/mcnet/mcnet.py:36-38, 45-47) read from the pooled
+ *                   output of the layer before it where it lies -- no stack of shifted copies.  The plane must carry the
+ *                   halo: image row 0 at row k/2, so in_oy = 1; image column 0 at column in_ox + k/2 - 1 with in_ox even
+ *                   and >= 2; in_h >= H + in_oy + 1 + 3 (shift_s - 1), in_w >= W + in_ox + 2 + 3 (shift_s - 1), halo zero.
+ *   ypool, pool_*   2x2 max pool of the activated output written into a plane of pool_h x pool_w with its origin at
+ *                   (pool_oy, pool_ox) (pool_h = 0: a plain [N, K, H/2, W/2] tensor);
+ *   addx, y2        y2 [N, K, H, W] = y + fixed_unpooling(addx), addx [N, K, H/2, W/2] landing on the even (2i, 2j) sites:
+ *                   DecCnn's unpool + residual add (src/models/mcnet/mcnet.py:234-236, 240-256) as a second output of the
+ *                   Residual block's last convolution (mcnet.py:172-176). */
+int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_s, const float* U, const float* bias, float* y,
+                                float* ypool, int pool_h, int pool_w, int pool_oy, int pool_ox, const float* addx, float* y2, int N,
+                                int C, int K, int H, int W, int in_h, int in_w, int in_oy, int in_ox, int act, void* hip_stream);
 /* Benchmarking: 0 keeps every layer on the 64-channel x 64-tile workgroup shape; 1 (default) lets layers whose K is a
  * multiple of 128 use the 128 x 32 shape.  Returns the previous value. */
 int tai_conv3x3_wino_set_tall(int on);

@@ -93,3 +93,27 @@ def test_cin1_fused_maxpool(k, shape):
         y, yp = conv_bias_act_maxpool(x, w, b, k // 2, 'relu')
         assert torch.equal(y, conv_bias_act(x, w, b, k // 2, 'relu'))
         assert torch.equal(yp, F.max_pool2d(y, 2))
+
+
+@pytest.mark.parametrize('origin', [(2, 3), (3, 4), (0, 0)])
+def test_cin1_pool_into_a_halo_plane(origin):
+    """The pooled output written into a larger plane at an (odd or even) origin; everything outside the window untouched."""
+    from video_frame_inpainting_amd import _native
+    L = _native.lib()
+    N, Co, H, W, k = 2, 16, 16, 24, 5
+    oy, ox = origin
+    ph, pw = H // 2 + oy + 3, W // 2 + ox + 5
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(N, 1, H, W, generator=g).cuda()
+    w = torch.randn(Co, 1, k, k, generator=g).cuda() * 0.2
+    b = torch.randn(Co, generator=g).cuda()
+    y = torch.empty(N, Co, H, W, device='cuda')
+    plane = torch.full((N, Co, ph, pw), 7.0, device='cuda')
+    _native.check(L.tai_conv_cin1_forward_maxpool_window(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), plane.data_ptr(),
+                                                        N, Co, H, W, k, 1, ph, pw, oy, ox, torch.cuda.current_stream().cuda_stream), 'cin1')
+    ref = torch.relu(F.conv2d(x, w, b, padding=k // 2))
+    assert float((y - ref).abs().max()) <= 1e-5
+    assert torch.equal(plane[:, :, oy:oy + H // 2, ox:ox + W // 2], F.max_pool2d(y, 2))
+    mask = torch.ones_like(plane, dtype=torch.bool)
+    mask[:, :, oy:oy + H // 2, ox:ox + W // 2] = False
+    assert bool((plane[mask] == 7.0).all())

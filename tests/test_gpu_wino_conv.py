@@ -250,3 +250,93 @@ def test_tall_workgroup_shape_gives_the_same_bits(shape):
         L.tai_conv3x3_wino_set_tall(1)
     assert torch.equal(got, ref)
     _check(x, w, b, 'relu')
+
+
+# ---- round 2: displaced reads of a halo-carrying plane (5x5 / 7x7 without a stack of shifted copies), pooled output
+# written into the next layer's plane, unpool + residual add as a second output ----------------------------------------
+def test_motion_encoder_chain_matches_the_stage_by_stage_ops(monkeypatch):
+    """MotionEnc (mcnet.py:14-60) through conv_ops.motion_enc_chain: every stage against ATen on the same operands in
+    fp64, twice with different inputs (the cached planes' halos must still be zero the second time), and the displaced-
+    read path against the shifted-copy path bit for bit (same channel order, same chunks)."""
+    from video_frame_inpainting_amd import conv_ops
+    from video_frame_inpainting_amd.mcnet import MotionEnc
+    from video_frame_inpainting_amd import synthetic
+    monkeypatch.setattr(conv_ops, 'WINO_MIN_WORKGROUPS', 1)      # (a speed heuristic: small problems stay on MIOpen)
+    enc = synthetic.seeded_init(MotionEnc(16), 3).cuda()
+    convs = [enc.dyn_conv1.convs()[0], enc.dyn_conv2.convs()[0], enc.dyn_conv3.convs()[0]]
+    for seed in (1, 2):
+        x = torch.randn(6, 1, 64, 96, generator=torch.Generator().manual_seed(seed)).cuda()
+        with torch.no_grad():
+            got = conv_ops.motion_enc_chain(x, *convs)
+            assert got is not None
+            p3, (c1, c2, c3) = got
+            r1 = torch.relu(F.conv2d(x.double(), convs[0].weight.double(), convs[0].bias.double(), padding=2))
+            r2 = torch.relu(F.conv2d(F.max_pool2d(r1, 2), convs[1].weight.double(), convs[1].bias.double(), padding=2))
+            r3 = torch.relu(F.conv2d(F.max_pool2d(r2, 2), convs[2].weight.double(), convs[2].bias.double(), padding=3))
+            for a, b in ((c1, r1), (c2, r2), (c3, r3), (p3, F.max_pool2d(r3, 2))):
+                assert a.shape == b.shape
+                assert float((a.double() - b).abs().max()) <= 2e-5 * float(b.abs().max())
+            # the shifted-copy path of round 1 on the same pooled inputs: identical arithmetic
+            y2, yp2 = conv_ops._kxk_as_wino(F.max_pool2d(c1, 2), convs[1].weight, convs[1].bias, 'relu', True)
+            assert torch.equal(y2, c2)
+            y3, yp3 = conv_ops._kxk_as_wino(yp2, convs[2].weight, convs[2].bias, 'relu', True)
+            assert torch.equal(y3, c3) and torch.equal(yp3, p3)
+            out = enc(x)                     # the module takes the chain
+            assert torch.equal(out[0], p3)
+
+
+def test_motion_encoder_chain_declines_what_it_cannot_run(monkeypatch):
+    from video_frame_inpainting_amd import conv_ops
+    monkeypatch.setattr(conv_ops, 'WINO_MIN_WORKGROUPS', 1)
+    from video_frame_inpainting_amd.mcnet import MotionEnc
+    enc = MotionEnc(4).cuda()                 # 4 channels: not a multiple of the 8-channel chunk
+    convs = [enc.dyn_conv1.convs()[0], enc.dyn_conv2.convs()[0], enc.dyn_conv3.convs()[0]]
+    x = torch.randn(2, 1, 32, 32).cuda()
+    with torch.no_grad():
+        assert conv_ops.motion_enc_chain(x, *convs) is None
+        p3, res = enc(x)                      # falls back to the stage-by-stage path
+    assert p3.shape == (2, 16, 4, 4)
+    enc16 = MotionEnc(16).cuda()
+    c16 = [enc16.dyn_conv1.convs()[0], enc16.dyn_conv2.convs()[0], enc16.dyn_conv3.convs()[0]]
+    assert conv_ops.motion_enc_chain(torch.randn(6, 1, 64, 96).cuda().requires_grad_(), *c16) is None     # autograd: stock ops
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 64, 32, 32), (2, 16, 128, 64, 64), (5, 24, 51, 12, 20)])
+@pytest.mark.parametrize('nparts', [1, 2])
+def test_unpool_add_second_output(shape, nparts, monkeypatch):
+    from video_frame_inpainting_amd import conv_ops
+    monkeypatch.setattr(conv_ops, 'WINO_MIN_WORKGROUPS', 1)
+    N, C, K, H, W = shape
+    g = torch.Generator().manual_seed(C + K)
+    parts = [torch.randn(N, C // nparts, H, W, generator=g).cuda() for _ in range(nparts)]
+    w = (torch.randn(K, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda()
+    b = torch.randn(K, generator=g).cuda()
+    below = torch.randn(N, K, H // 2, W // 2, generator=g).cuda()
+    with torch.no_grad():
+        y, y2 = conv_ops.conv_bias_unpool_add(tuple(parts) if nparts > 1 else parts[0], w, b, 1, below)
+        ref = conv_ops.conv_bias_act(torch.cat(parts, 1), w, b, 1, None)
+    want = ref.clone()
+    want[:, :, 0::2, 0::2] += below
+    assert torch.equal(y, ref)                # same kernel, same arithmetic
+    assert torch.equal(y2, want)
+
+
+def test_general_entry_point_rejects_bad_arguments():
+    import ctypes
+    from video_frame_inpainting_amd import _native
+    L = _native.lib()
+    t = torch.zeros(1 << 16, device='cuda')
+    p = t.data_ptr()
+    xs = (ctypes.c_void_p * 1)(p)
+    s = torch.cuda.current_stream().cuda_stream
+    ok = dict(nparts=1, shift=2, N=1, C=4 * 8, K=8, H=8, W=8, in_h=13, in_w=16, in_oy=1, in_ox=2)
+
+    def call(**kw):
+        a = dict(ok, **kw)
+        return L.tai_conv3x3_wino_forward_ex(xs, a['nparts'], a['shift'], p, p, p, None, 0, 0, 0, 0, None, None, a['N'], a['C'], a['K'],
+                                             a['H'], a['W'], a['in_h'], a['in_w'], a['in_oy'], a['in_ox'], 0, s)
+    assert call() == 0
+    assert call(shift=4) == -1 and call(C=4 * 6) == -1                   # shift_s in {2, 3}; C / shift_s^2 a multiple of 8
+    assert call(in_h=12) == -1 and call(in_w=14) == -1 and call(in_ox=0) == -1      # the plane must hold the halo
+    assert L.tai_conv3x3_wino_forward_ex(xs, 1, 0, p, p, p, None, 0, 0, 0, 0, p, None, 1, 8, 8, 8, 8, 8, 8, 0, 0, 0, s) == -1   # addx without y2
+    torch.cuda.synchronize()

@@ -87,6 +87,10 @@ def lib():
     L.tai_conv3x3_wino_forward_maxpool.restype = I
     L.tai_conv3x3_wino_forward_window.argtypes = [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, V]
     L.tai_conv3x3_wino_forward_window.restype = I
+    L.tai_conv3x3_wino_forward_ex.argtypes = [P, I, I, P, P, P, P, I, I, I, I, P, P] + [I] * 10 + [V]
+    L.tai_conv3x3_wino_forward_ex.restype = I
+    L.tai_conv_cin1_forward_maxpool_window.argtypes = [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, V]
+    L.tai_conv_cin1_forward_maxpool_window.restype = I
     L.tai_conv3x3_wino_set_tall.argtypes = [I]
     L.tai_conv3x3_wino_set_tall.restype = I
     L.tai_conv3x3_wino_forward_parts.argtypes = [P, I, P, P, P, I, I, I, I, I, I, V]

@@ -117,6 +117,117 @@ def _kxk_as_wino(x, weight, bias, act, pool):
     return (y, yp) if pool else y
 
 
+_HALO_PLANES = {}
+
+
+def halo_geometry(H, W, k):
+    """The plane through which a k x k (k = 5, 7) "same" convolution over an H x W image reads its S x S blocks of 3 x 3
+    taps as displaced 3 x 3 convolutions (tai_conv3x3_wino_forward_ex, shift_s): -> (S, top, left, in_h, in_w).  Image
+    pixel (0, 0) sits at (top, left) = (k/2, k/2 + 1): block (0, 0)'s centre tap of output (0, 0) is then at (1, 2) -- the
+    kernel's (in_oy, in_ox), in_ox even -- and block (a, b) reads 3a rows / 3b columns further, up to row H + 1 + 3 (S - 1)
+    and column W + 3 + 3 (S - 1), all inside the plane; everything outside the image is zero."""
+    S = (k + 2) // 3
+    in_h, in_w = H + 2 + 3 * (S - 1), W + 4 + 3 * (S - 1)
+    return S, k // 2, k // 2 + 1, in_h, in_w + (in_w & 1)
+
+
+def halo_plane(N, C, H, W, k, device):
+    """A cached zero-filled [N, C, in_h, in_w] buffer for halo_geometry(H, W, k): producers write the image into its
+    interior (pooled-output window of the convolution before), the halo stays zero from the allocation on.  One buffer
+    per (shape, device, stream): the consumer runs right behind the producer on that stream."""
+    S, top, left, in_h, in_w = halo_geometry(H, W, k)
+    key = (N, C, in_h, in_w, str(device), torch.cuda.current_stream(device).cuda_stream)
+    buf = _HALO_PLANES.get(key)
+    if buf is None:
+        buf = torch.zeros((N, C, in_h, in_w), dtype=torch.float32, device=device)
+        _HALO_PLANES[key] = buf
+    return buf
+
+
+def _no_grad_needed(*tensors):
+    return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors))
+
+
+def motion_enc_chain(diff, conv1, conv2, conv3):
+    """MotionEnc's three convolution + ReLU + 2x2 max pool stages (mcnet.py:28-60: 5x5 1 -> g, 5x5 g -> 2g, 7x7 2g -> 4g)
+    with each pooled output written straight into the halo-carrying plane the next stage reads through displaced 3 x 3
+    blocks: no pooled tensor is copied, padded or stacked in between.  Returns (pooled3, [c1, c2, c3]) or None when
+    the shapes do not qualify (the caller then runs the stages one by one)."""
+    if not (torch.is_tensor(diff) and diff.is_cuda and diff.dtype == torch.float32 and diff.dim() == 4 and diff.shape[1] == 1):
+        return None
+    ws = [conv1.weight, conv2.weight, conv3.weight]
+    bs = [conv1.bias, conv2.bias, conv3.bias]
+    if any(b is None for b in bs) or not _no_grad_needed(diff, *ws, *bs):
+        return None
+    N, _, H, W = diff.shape
+    g = ws[0].shape[0]
+    if not (tuple(ws[0].shape) == (g, 1, 5, 5) and tuple(ws[1].shape) == (2 * g, g, 5, 5) and tuple(ws[2].shape) == (4 * g, 2 * g, 7, 7)
+            and conv1.padding[0] == 2 and conv2.padding[0] == 2 and conv3.padding[0] == 3
+            and H % 8 == 0 and W % 8 == 0 and g % 8 == 0 and g >= 16):
+        return None
+    H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+    S2, top2, left2, ih2, iw2 = halo_geometry(H2, W2, 5)
+    S3, top3, left3, ih3, iw3 = halo_geometry(H4, W4, 7)
+    if not (_wino_ok(N, S2 * S2 * g, 2 * g, H2, W2, 3, 3, 1) and _wino_ok(N, S3 * S3 * 2 * g, 4 * g, H4, W4, 3, 3, 1)
+            and N * g * ih2 * iw2 < 2 ** 29 and N * 2 * g * ih3 * iw3 < 2 ** 29 and N * g * H * W < 2 ** 29):
+        return None
+    L = _native.lib()
+    dev = diff.device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    diff = diff.contiguous()
+    c1 = torch.empty((N, g, H, W), dtype=torch.float32, device=dev)
+    c2 = torch.empty((N, 2 * g, H2, W2), dtype=torch.float32, device=dev)
+    c3 = torch.empty((N, 4 * g, H4, W4), dtype=torch.float32, device=dev)
+    p3 = torch.empty((N, 4 * g, H4 // 2, W4 // 2), dtype=torch.float32, device=dev)
+    plane2 = halo_plane(N, g, H2, W2, 5, dev)
+    plane3 = halo_plane(N, 2 * g, H4, W4, 7, dev)
+    U2, U3 = _wino_weights_kxk(ws[1]), _wino_weights_kxk(ws[2])
+    xs2 = (ctypes.c_void_p * 1)(plane2.data_ptr())
+    xs3 = (ctypes.c_void_p * 1)(plane3.data_ptr())
+    with torch.cuda.device(dev):
+        _native.check(L.tai_conv_cin1_forward_maxpool_window(diff.data_ptr(), ws[0].contiguous().data_ptr(), bs[0].data_ptr(),
+                                                            c1.data_ptr(), plane2.data_ptr(), N, g, H, W, 5, 1, ih2, iw2, top2, left2,
+                                                            stream), 'tai_conv_cin1_forward_maxpool_window')
+        _native.check(L.tai_conv3x3_wino_forward_ex(xs2, 1, S2, U2.data_ptr(), bs[1].data_ptr(), c2.data_ptr(), plane3.data_ptr(),
+                                                   ih3, iw3, top3, left3, None, None, N, S2 * S2 * g, 2 * g, H2, W2, ih2, iw2, 1, 2, 1,
+                                                   stream), 'tai_conv3x3_wino_forward_ex')
+        _native.check(L.tai_conv3x3_wino_forward_ex(xs3, 1, S3, U3.data_ptr(), bs[2].data_ptr(), c3.data_ptr(), p3.data_ptr(),
+                                                   0, 0, 0, 0, None, None, N, S3 * S3 * 2 * g, 4 * g, H4, W4, ih3, iw3, 1, 2, 1,
+                                                   stream), 'tai_conv3x3_wino_forward_ex')
+    return p3, [c1, c2, c3]
+
+
+def conv_bias_unpool_add(x, weight, bias, padding, addx):
+    """(y, y + fixed_unpooling(addx)) with y = conv(x) + bias, no activation: the last convolution of a Residual block
+    (mcnet.py:172-176) and DecCnn's unpool + residual add (mcnet.py:234-236) -- a Winograd tile is one unpooling cell, so
+    the sum is a second output of the convolution's epilogue.  ``x`` may be a tuple of cat operands."""
+    parts = list(x) if isinstance(x, (list, tuple)) else [x]
+    x0 = parts[0]
+    Co, Ci, kh, kw = weight.shape
+    N, Cp, H, W = x0.shape
+    fused = (x0.is_cuda and x0.dtype == torch.float32 and bias is not None and addx.is_cuda and addx.dtype == torch.float32
+             and tuple(addx.shape) == (N, Co, H // 2, W // 2) and len(parts) <= 4 and Cp * len(parts) == Ci
+             and (len(parts) == 1 or Cp % 8 == 0) and all(q.shape == x0.shape and q.dtype == x0.dtype for q in parts)
+             and _no_grad_needed(weight, bias, addx, *parts) and _wino_ok(N, Ci, Co, H, W, kh, kw, padding)
+             and N * Co * H * W < 2 ** 29)
+    if not fused:
+        from .mcnet import unpool2x_add
+        y = conv_bias_act(x, weight, bias, padding, None)
+        return y, unpool2x_add(addx, y)
+    L = _native.lib()
+    parts = [q.contiguous() for q in parts]
+    addx = addx.contiguous()
+    U = _wino_weights(weight, False)
+    y = torch.empty((N, Co, H, W), dtype=torch.float32, device=x0.device)
+    y2 = torch.empty_like(y)
+    ptrs = (ctypes.c_void_p * len(parts))(*[q.data_ptr() for q in parts])
+    with torch.cuda.device(x0.device):
+        _native.check(L.tai_conv3x3_wino_forward_ex(ptrs, len(parts), 0, U.data_ptr(), bias.data_ptr(), y.data_ptr(), None, 0, 0, 0, 0,
+                                                   addx.data_ptr(), y2.data_ptr(), N, Ci, Co, H, W, H, W, 0, 0, 0,
+                                                   torch.cuda.current_stream(x0.device).cuda_stream), 'tai_conv3x3_wino_forward_ex')
+    return y, y2
+
+
 def _kxk_ok(N, Ci, Co, H, W, kh, kw, padding):
     S = (kh + 2) // 3
     return (kh == kw and kh in (5, 7) and padding == kh // 2 and W % 4 == 0 and Ci >= 16

@@ -314,23 +314,31 @@ int tai_conv_cin1_forward(const float* x, const float* weight, const float* bias
     return check_launch("conv_cin1");
 }
 
-int tai_conv_cin1_forward_maxpool(const float* x, const float* weight, const float* bias, float* y, float* ypool, int N, int Co,
-                                  int H, int W, int k, int act, void* hip_stream) {
+int tai_conv_cin1_forward_maxpool_window(const float* x, const float* weight, const float* bias, float* y, float* ypool, int N,
+                                         int Co, int H, int W, int k, int act, int pool_h, int pool_w, int pool_oy, int pool_ox,
+                                         void* hip_stream) {
     g_err[0] = 0;
     if (!x || !weight || !bias || !y || !ypool) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
     if (N <= 0 || Co <= 0 || H <= 0 || W <= 0 || W % 4 != 0 || H % 2 != 0 || (k != 3 && k != 5) || act < 0 || act > 1)
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv_cin1_maxpool: needs W % 4 == 0, even H, k in {3, 5}, act in {0, 1}");
+    if (pool_oy < 0 || pool_ox < 0 || pool_h < H / 2 + pool_oy || pool_w < W / 2 + pool_ox)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv_cin1_maxpool: bad pooled-output window");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const long long work = (long long)N * (H / 2) * (W / 4);
     const int blocks = (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192);
     const int cgroups = (work < 4 * 262144 && Co >= 16) ? 4 : 1;
-#define TAI_LAUNCH_CIN1P(K, A) hipLaunchKernelGGL((thin::conv_cin1_pool<K, A>), dim3(blocks, cgroups), dim3(256), 0, s, x, weight, bias, y, ypool, N, Co, H, W)
+#define TAI_LAUNCH_CIN1P(K, A) hipLaunchKernelGGL((thin::conv_cin1_pool<K, A>), dim3(blocks, cgroups), dim3(256), 0, s, x, weight, bias, y, ypool, N, Co, H, W, pool_h, pool_w, pool_oy, pool_ox)
     if (k == 3 && act == 0) TAI_LAUNCH_CIN1P(3, 0);
     else if (k == 3) TAI_LAUNCH_CIN1P(3, 1);
     else if (act == 0) TAI_LAUNCH_CIN1P(5, 0);
     else TAI_LAUNCH_CIN1P(5, 1);
 #undef TAI_LAUNCH_CIN1P
     return check_launch("conv_cin1_maxpool");
+}
+
+int tai_conv_cin1_forward_maxpool(const float* x, const float* weight, const float* bias, float* y, float* ypool, int N, int Co,
+                                  int H, int W, int k, int act, void* hip_stream) {
+    return tai_conv_cin1_forward_maxpool_window(x, weight, bias, y, ypool, N, Co, H, W, k, act, H / 2, W / 2, 0, 0, hip_stream);
 }
 
 int tai_unpool2x_add(const float* x, const float* res, float* out, long long planes, int h, int w, void* hip_stream) {
@@ -399,9 +407,15 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
     return check_launch("wino_transform_weights");
 }
 
+struct WinoExtras {                       // optional arguments of the general entry point (tai_conv3x3_wino_forward_ex)
+    int shift_s = 0;                      // > 0: ONE input tensor read shift_s x shift_s times, displaced by (3a, 3b)
+    int pool_h = 0, pool_w = 0, pool_oy = 0, pool_ox = 0;     // ypool plane and origin (0: H/2 x W/2 at (0, 0))
+    const float* addx = nullptr;          // y2 = y + fixed_unpooling(addx)
+    float* y2 = nullptr;
+};
 static int wino_forward_impl(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C,
                              int K, int H, int W, int act, void* hip_stream, long long* stamps, float* ypool = nullptr,
-                             int in_h = 0, int in_w = 0, int in_oy = 0, int in_ox = 0);
+                             int in_h = 0, int in_w = 0, int in_oy = 0, int in_ox = 0, const WinoExtras& ex = WinoExtras());
 static std::atomic<int> g_wino_tall{1};            // 1: use the 128 x 32 workgroup shape when K is a multiple of 128
 int tai_conv3x3_wino_set_tall(int on) { return g_wino_tall.exchange(on ? 1 : 0, std::memory_order_relaxed); }
 static std::atomic<int> g_wino_timeline_skip{0};   // timeline launches only: loop parts left out (wino_conv.hip.inc, SKIP)
@@ -454,13 +468,43 @@ int tai_conv3x3_wino_forward_timeline(const float* x, const float* U, const floa
     return wino_forward_impl(xs, 1, U, bias, y, N, C, K, H, W, 1, hip_stream, stamps);
 }
 
+int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_s, const float* U, const float* bias, float* y,
+                                float* ypool, int pool_h, int pool_w, int pool_oy, int pool_ox, const float* addx, float* y2, int N,
+                                int C, int K, int H, int W, int in_h, int in_w, int in_oy, int in_ox, int act, void* hip_stream) {
+    if (!xs || nparts < 1 || nparts > 4 || (shift_s != 0 && nparts != 1))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: 1 to 4 input parts, or one tensor read shift_s x shift_s times");
+    if (nparts > 1 && (C % nparts != 0 || (C / nparts) % 8 != 0))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: parts must have equal channel counts, a multiple of 8");
+    if (shift_s != 0 && (shift_s < 2 || shift_s > 3 || C % (shift_s * shift_s) != 0 || (C / (shift_s * shift_s)) % 8 != 0))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: shift_s in {2, 3}, C = shift_s^2 x (a multiple of 8)");
+    if ((addx == nullptr) != (y2 == nullptr)) return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: addx and y2 go together");
+    const float* p[4];
+    for (int i = 0; i < 4; ++i) {
+        p[i] = xs[i < nparts ? i : 0];
+        if (!p[i]) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    }
+    WinoExtras ex;
+    ex.shift_s = shift_s; ex.pool_h = pool_h; ex.pool_w = pool_w; ex.pool_oy = pool_oy; ex.pool_ox = pool_ox; ex.addx = addx; ex.y2 = y2;
+    return wino_forward_impl(p, nparts, U, bias, y, N, C, K, H, W, act, hip_stream, nullptr, ypool, in_h, in_w, in_oy, in_ox, ex);
+}
+
 static int wino_forward_impl(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C,
                              int K, int H, int W, int act, void* hip_stream, long long* stamps, float* ypool, int in_h,
-                             int in_w, int in_oy, int in_ox) {
+                             int in_w, int in_oy, int in_ox, const WinoExtras& ex) {
     if (in_h == 0) { in_h = H; in_w = W; }
     g_err[0] = 0;
     if (!xs[0] || !U || !bias || !y) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
-    const int cpart = C / nparts;
+    const int S = ex.shift_s;
+    const int cpart = S ? C / (S * S) : C / nparts;
+    const int pool_h = ex.pool_h ? ex.pool_h : H / 2, pool_w = ex.pool_h ? ex.pool_w : W / 2;
+    const int pool_oy = ex.pool_h ? ex.pool_oy : 0, pool_ox = ex.pool_h ? ex.pool_ox : 0;
+    if (ypool && (pool_oy < 0 || pool_ox < 0 || pool_h < H / 2 + pool_oy || pool_w < W / 2 + pool_ox))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: bad pooled-output window");
+    if (ypool && (long long)N * K * pool_h * pool_w >= (1LL << 29))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: pooled tensor too large (2^29 elements or more)");
+    // displaced reads stay inside the plane: rows up to H + in_oy + 3 (S - 1), columns up to W + 1 + in_ox + 3 (S - 1)
+    if (S && (in_oy < 1 || in_ox < 2 || in_h < H + in_oy + 1 + 3 * (S - 1) || in_w < W + in_ox + 2 + 3 * (S - 1)))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: the input plane does not hold the halo of the displaced reads");
     if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2 || act < 0 || act > 2)
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: needs even H and W, act in {0, 1, 2}");
     if (in_h < H + in_oy || in_w < W + in_ox || in_oy < 0 || in_ox < 0 || in_ox % 2 || in_w % 2)
@@ -475,51 +519,47 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
     const bool tall = Kpad % wino::TTM == 0 && g_wino_tall.load(std::memory_order_relaxed) != 0;
     const int skip = g_wino_timeline_skip.load(std::memory_order_relaxed);
     (void)skip;
-#define TAI_LAUNCH_WINO(A, D, ...)                                                                                     \
+    const int pmode = S ? 2 : (nparts > 1 ? 1 : 0);
+#define TAI_WINO_ARGS xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, Kpad, nchunks
+#define TAI_WINO_TAIL stamps, pool_h, pool_w, pool_oy, pool_ox, ex.addx, ex.y2, S
+#define TAI_LAUNCH_WINO(A, D, SK, Q)                                                                                     \
     do {                                                                                                               \
-        if (int rc = allow_lds(wino::conv3x3<A, D, ##__VA_ARGS__>, wino::LDS_BYTES)) return rc;                          \
-        hipLaunchKernelGGL((wino::conv3x3<A, D, ##__VA_ARGS__>), dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::LDS_BYTES, s,  \
-                           xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, Kpad, nchunks, kblocks, stamps);                              \
+        if (tall) {      /* 128-channel x 32-tile workgroups (half the patch transform and LDS writes per MFMA) */    \
+            const long long ttb = (tiles + wino::TTN - 1) / wino::TTN;                                                 \
+            const int tkb = Kpad / wino::TTM;                                                                          \
+            if (int rc = allow_lds(wino::conv3x3<A, D, SK, Q, true>, wino::TLDS_BYTES)) return rc;                     \
+            hipLaunchKernelGGL((wino::conv3x3<A, D, SK, Q, true>), dim3((unsigned)(ttb * tkb)), dim3(256), wino::TLDS_BYTES, s, \
+                               TAI_WINO_ARGS, tkb, TAI_WINO_TAIL);                                                     \
+        } else {                                                                                                       \
+            if (int rc = allow_lds(wino::conv3x3<A, D, SK, Q, false>, wino::LDS_BYTES)) return rc;                     \
+            hipLaunchKernelGGL((wino::conv3x3<A, D, SK, Q, false>), dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::LDS_BYTES, s, \
+                               TAI_WINO_ARGS, kblocks, TAI_WINO_TAIL);                                                 \
+        }                                                                                                              \
     } while (0)
-    if (tall) {
-        // 128-channel x 32-tile workgroups (half the patch transform and LDS writes per MFMA) when K allows
-        const long long ttb = (tiles + wino::TTN - 1) / wino::TTN;
-        const int tkb = Kpad / wino::TTM;
-#define TAI_LAUNCH_WINO_TALL(A, Q, D, S)                                                                                 \
-    do {                                                                                                               \
-        if (int rc = allow_lds(wino::conv3x3<A, D, S, Q, true>, wino::TLDS_BYTES)) return rc;                          \
-        hipLaunchKernelGGL((wino::conv3x3<A, D, S, Q, true>), dim3((unsigned)(ttb * tkb)), dim3(256), wino::TLDS_BYTES, s, \
-                           xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, Kpad, \
-                           nchunks, tkb, stamps);                                                                      \
+#define TAI_LAUNCH_WINO_ACT(D, SK, Q)                                   \
+    do {                                                                \
+        if (act == 0) TAI_LAUNCH_WINO(0, D, SK, Q);                     \
+        else if (act == 1) TAI_LAUNCH_WINO(1, D, SK, Q);                \
+        else TAI_LAUNCH_WINO(2, D, SK, Q);                              \
     } while (0)
+    if (stamps) {        // timeline launches (tools/wino_timeline.py): ReLU, one tensor
 #ifdef TAI_TIMING_VARIANTS
-        if (stamps && skip == 1) TAI_LAUNCH_WINO_TALL(1, 0, 1, 1);
-        else if (stamps && skip == 2) TAI_LAUNCH_WINO_TALL(1, 0, 1, 2);
-        else if (stamps && skip == 4) TAI_LAUNCH_WINO_TALL(1, 0, 1, 4);
-        else if (stamps && skip == 5) TAI_LAUNCH_WINO_TALL(1, 0, 1, 5);
-        else if (stamps && skip == 7) TAI_LAUNCH_WINO_TALL(1, 0, 2, 0);
+        if (skip == 1) TAI_LAUNCH_WINO(1, 1, 1, 0);
+        else if (skip == 2) TAI_LAUNCH_WINO(1, 1, 2, 0);
+        else if (skip == 4) TAI_LAUNCH_WINO(1, 1, 4, 0);
+        else if (skip == 5) TAI_LAUNCH_WINO(1, 1, 5, 0);
+        else if (skip == 7) TAI_LAUNCH_WINO(1, 2, 0, 0);
         else
 #endif
-        if (stamps) TAI_LAUNCH_WINO_TALL(1, 0, 1, 0);
-        else if (nparts > 1) { if (act == 0) TAI_LAUNCH_WINO_TALL(0, 1, 0, 0); else if (act == 1) TAI_LAUNCH_WINO_TALL(1, 1, 0, 0); else TAI_LAUNCH_WINO_TALL(2, 1, 0, 0); }
-        else { if (act == 0) TAI_LAUNCH_WINO_TALL(0, 0, 0, 0); else if (act == 1) TAI_LAUNCH_WINO_TALL(1, 0, 0, 0); else TAI_LAUNCH_WINO_TALL(2, 0, 0, 0); }
-#undef TAI_LAUNCH_WINO_TALL
+        TAI_LAUNCH_WINO(1, 1, 0, 0);
     }
-#ifdef TAI_TIMING_VARIANTS
-    else if (stamps && skip == 1) TAI_LAUNCH_WINO(1, 1, 1);
-    else if (stamps && skip == 2) TAI_LAUNCH_WINO(1, 1, 2);
-    else if (stamps && skip == 4) TAI_LAUNCH_WINO(1, 1, 4);
-    else if (stamps && skip == 7) TAI_LAUNCH_WINO(1, 2, 0);
-    else if (stamps && skip == 5) TAI_LAUNCH_WINO(1, 1, 5);
-#endif
-    else if (stamps) TAI_LAUNCH_WINO(1, 1);
-    else if (nparts > 1 && act == 0) TAI_LAUNCH_WINO(0, 0, 0, 1);
-    else if (nparts > 1 && act == 1) TAI_LAUNCH_WINO(1, 0, 0, 1);
-    else if (nparts > 1) TAI_LAUNCH_WINO(2, 0, 0, 1);
-    else if (act == 0) TAI_LAUNCH_WINO(0, 0);
-    else if (act == 1) TAI_LAUNCH_WINO(1, 0);
-    else TAI_LAUNCH_WINO(2, 0);
+    else if (pmode == 2) TAI_LAUNCH_WINO_ACT(0, 0, 2);
+    else if (pmode == 1) TAI_LAUNCH_WINO_ACT(0, 0, 1);
+    else TAI_LAUNCH_WINO_ACT(0, 0, 0);
+#undef TAI_LAUNCH_WINO_ACT
 #undef TAI_LAUNCH_WINO
+#undef TAI_WINO_TAIL
+#undef TAI_WINO_ARGS
     return check_launch("conv3x3_wino");
 }
 

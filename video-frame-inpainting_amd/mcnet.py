@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .conv_ops import conv_bias_act, conv_bias_act_maxpool
+from .conv_ops import conv_bias_act, conv_bias_act_maxpool, conv_bias_unpool_add, motion_enc_chain
 from .util import gray01
 
 
@@ -88,6 +88,9 @@ class MotionEnc(nn.Module):
         self.dyn_conv3 = IndexedConvs([(1, nn.Conv2d(gf_dim * 2, gf_dim * 4, 7, padding=3))])
 
     def forward(self, input_diff):
+        fused = motion_enc_chain(input_diff, self.dyn_conv1.convs()[0], self.dyn_conv2.convs()[0], self.dyn_conv3.convs()[0])
+        if fused is not None:       # the three stages hand their pooled outputs over in halo-carrying planes (conv_ops)
+            return fused
         c1, p1 = _conv_relu_chain_pooled(input_diff, self.dyn_conv1.convs())
         c2, p2 = _conv_relu_chain_pooled(p1, self.dyn_conv2.convs())
         c3, p3 = _conv_relu_chain_pooled(p2, self.dyn_conv3.convs())
@@ -135,6 +138,12 @@ class Residual(nn.Module):
     def forward(self, input_dyn, input_cont):
         return _conv_relu_chain((input_dyn, input_cont), self.res.convs(), last_act=None)   # conv(cat(..)) without the cat
 
+    def forward_unpool_add(self, input_dyn, input_cont, below):
+        """(res, res + fixed_unpooling(below)): the block's output and the sum DecCnn forms from it (mcnet.py:234-236)."""
+        c0, c1 = self.res.convs()
+        mid = conv_bias_act((input_dyn, input_cont), c0.weight, c0.bias, c0.padding[0], 'relu')
+        return conv_bias_unpool_add(mid, c1.weight, c1.bias, c1.padding[0], below)
+
 
 class DecCnn(nn.Module):
     """mcnet.py:188-256: three unpool(+residual) stages of 3x3 transposed convs, ReLU inside, Tanh at the end."""
@@ -157,6 +166,10 @@ class DecCnn(nn.Module):
         x = self._stage(unpool2x_add(comb, res3), self.dec3.convs(), 'relu')
         x = self._stage(unpool2x_add(x, res2), self.dec2.convs(), 'relu')
         return self._stage(unpool2x_add(x, res1), self.dec1.convs(), 'tanh')
+
+    def stage(self, index, x):
+        """The transposed-convolution stack of stage 3, 2 or 1 on an input that already is unpool(below) + residual."""
+        return self._stage(x, (self.dec1, self.dec2, self.dec3)[index - 1].convs(), 'tanh' if index == 1 else 'relu')
 
     fixed_unpooling = staticmethod(lambda x: unpool2x_add(x, x.new_zeros(x.shape[0], x.shape[1], 2 * x.shape[2], 2 * x.shape[3])))
 
@@ -239,11 +252,14 @@ class MCNet(nn.Module):
             h_tpl = self.comb_layers(h_dyn, h_cont)
             dyn.append(h_dyn)
             cont.append(h_cont)
-            res_1 = self.residual1(res_m[0], res_c[0])
-            res_2 = self.residual2(res_m[1], res_c[1])
-            res_3 = self.residual3(res_m[2], res_c[2])
+            # Residual blocks and decoder stages interleaved (the reference computes the three residuals first, then
+            # dec_cnn(h_tpl, res_1, res_2, res_3): mcnet.py:431-436): each residual's last convolution also emits
+            # unpool(stage below) + residual, the input of its decoder stage
+            res_3, u3 = self.residual3.forward_unpool_add(res_m[2], res_c[2], h_tpl)
+            res_2, u2 = self.residual2.forward_unpool_add(res_m[1], res_c[1], self.dec_cnn.stage(3, u3))
+            res_1, u1 = self.residual1.forward_unpool_add(res_m[0], res_c[0], self.dec_cnn.stage(2, u2))
             res.append([res_1, res_2, res_3])
-            x_hat = self.dec_cnn(h_tpl, res_1, res_2, res_3)
+            x_hat = self.dec_cnn.stage(1, u1)
             x_hat_gray = gray01(x_hat)
             diffs.append(x_hat_gray - xt_gray)
             xt, xt_gray = x_hat, x_hat_gray
