@@ -143,7 +143,8 @@ int tai_conv3x3_wino_forward_parts(const float* const* xs, int nparts, const flo
  *                   (pool_oy, pool_ox) (pool_h = 0: a plain [N, K, H/2, W/2] tensor);
  *   addx, y2        y2 [N, K, H, W] = y + fixed_unpooling(addx), addx [N, K, H/2, W/2] landing on the even (2i, 2j) sites:
  *                   DecCnn's unpool + residual add (src/models/mcnet/mcnet.py:234-236, 240-256) as a second output of the
- *                   Residual block's last convolution (mcnet.py:172-176). */
+ *                   Residual block's last convolution (mcnet.py:172-176).  With addx and y2 == NULL the sum is written to y
+ *                   (the plain convolution output is then not produced). */
 int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_s, const float* U, const float* bias, float* y,
                                 float* ypool, int pool_h, int pool_w, int pool_oy, int pool_ox, const float* addx, float* y2, int N,
                                 int C, int K, int H, int W, int in_h, int in_w, int in_oy, int in_ox, int act, void* hip_stream);

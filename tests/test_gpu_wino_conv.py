@@ -319,6 +319,12 @@ def test_unpool_add_second_output(shape, nparts, monkeypatch):
     want[:, :, 0::2, 0::2] += below
     assert torch.equal(y, ref)                # same kernel, same arithmetic
     assert torch.equal(y2, want)
+    with torch.no_grad():                     # only the sum wanted: it is written in place of the plain output
+        none, only = conv_ops.conv_bias_unpool_add(tuple(parts) if nparts > 1 else parts[0], w, b, 1, below, keep_plain=False)
+        assert none is None and torch.equal(only, want)
+        buf = torch.full((2 * N, K, H, W), float('nan'), device='cuda')            # result written into a batch slice
+        got = conv_ops.conv_bias_act(tuple(parts) if nparts > 1 else parts[0], w, b, 1, None, out=buf[N:])
+        assert got.data_ptr() == buf[N:].data_ptr() and torch.equal(buf[N:], ref) and bool(torch.isnan(buf[:N]).all())
 
 
 def test_general_entry_point_rejects_bad_arguments():
@@ -338,5 +344,5 @@ def test_general_entry_point_rejects_bad_arguments():
     assert call() == 0
     assert call(shift=4) == -1 and call(C=4 * 6) == -1                   # shift_s in {2, 3}; C / shift_s^2 a multiple of 8
     assert call(in_h=12) == -1 and call(in_w=14) == -1 and call(in_ox=0) == -1      # the plane must hold the halo
-    assert L.tai_conv3x3_wino_forward_ex(xs, 1, 0, p, p, p, None, 0, 0, 0, 0, p, None, 1, 8, 8, 8, 8, 8, 8, 0, 0, 0, s) == -1   # addx without y2
+    assert L.tai_conv3x3_wino_forward_ex(xs, 1, 0, p, p, p, None, 0, 0, 0, 0, None, p, 1, 8, 8, 8, 8, 8, 8, 0, 0, 0, s) == -1   # y2 without addx
     torch.cuda.synchronize()

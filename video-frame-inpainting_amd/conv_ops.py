@@ -197,10 +197,11 @@ def motion_enc_chain(diff, conv1, conv2, conv3):
     return p3, [c1, c2, c3]
 
 
-def conv_bias_unpool_add(x, weight, bias, padding, addx):
+def conv_bias_unpool_add(x, weight, bias, padding, addx, keep_plain=True):
     """(y, y + fixed_unpooling(addx)) with y = conv(x) + bias, no activation: the last convolution of a Residual block
     (mcnet.py:172-176) and DecCnn's unpool + residual add (mcnet.py:234-236) -- a Winograd tile is one unpooling cell, so
-    the sum is a second output of the convolution's epilogue.  ``x`` may be a tuple of cat operands."""
+    the sum is a second output of the convolution's epilogue.  ``x`` may be a tuple of cat operands.  ``keep_plain=False``:
+    only the sum is produced (returns (None, sum)): nothing reads the full-resolution residual itself."""
     parts = list(x) if isinstance(x, (list, tuple)) else [x]
     x0 = parts[0]
     Co, Ci, kh, kw = weight.shape
@@ -213,19 +214,19 @@ def conv_bias_unpool_add(x, weight, bias, padding, addx):
     if not fused:
         from .mcnet import unpool2x_add
         y = conv_bias_act(x, weight, bias, padding, None)
-        return y, unpool2x_add(addx, y)
+        return (y if keep_plain else None), unpool2x_add(addx, y)
     L = _native.lib()
     parts = [q.contiguous() for q in parts]
     addx = addx.contiguous()
     U = _wino_weights(weight, False)
     y = torch.empty((N, Co, H, W), dtype=torch.float32, device=x0.device)
-    y2 = torch.empty_like(y)
+    y2 = torch.empty_like(y) if keep_plain else None
     ptrs = (ctypes.c_void_p * len(parts))(*[q.data_ptr() for q in parts])
     with torch.cuda.device(x0.device):
         _native.check(L.tai_conv3x3_wino_forward_ex(ptrs, len(parts), 0, U.data_ptr(), bias.data_ptr(), y.data_ptr(), None, 0, 0, 0, 0,
-                                                   addx.data_ptr(), y2.data_ptr(), N, Ci, Co, H, W, H, W, 0, 0, 0,
+                                                   addx.data_ptr(), y2.data_ptr() if keep_plain else None, N, Ci, Co, H, W, H, W, 0, 0, 0,
                                                    torch.cuda.current_stream(x0.device).cuda_stream), 'tai_conv3x3_wino_forward_ex')
-    return y, y2
+    return (y, y2) if keep_plain else (None, y)
 
 
 def _kxk_ok(N, Ci, Co, H, W, kh, kw, padding):
@@ -240,6 +241,11 @@ WINO_MIN_WORKGROUPS = 96       # below this the 64x64-tile kernel leaves most of
 def _wino_ok(N, Ci, Co, H, W, kh, kw, padding):
     return (kh == kw == 3 and padding == 1 and H % 2 == 0 and W % 2 == 0 and Ci >= 8 and N * max(Ci, Co) * H * W < 2 ** 29
             and ((N * (H // 2) * (W // 2) + 63) // 64) * ((Co + 63) // 64) >= WINO_MIN_WORKGROUPS)
+
+
+def _usable_out(out, shape, like):
+    return (out is not None and tuple(out.shape) == tuple(shape) and out.is_contiguous() and out.dtype == like.dtype
+            and out.device == like.device)
 
 
 def _wino_launch(x, U, bias, N, Ci, Co, H, W, act):
@@ -323,11 +329,22 @@ def conv_bias_act_maxpool(x, weight, bias, padding, act):
     return y, F.max_pool2d(y, 2)
 
 
-def conv_bias_act(x, weight, bias, padding, act, transposed=False):
+def conv_bias_act(x, weight, bias, padding, act, transposed=False, out=None):
     """act(conv2d(x, weight, stride 1, padding) + bias), act in {None, 'relu', 'tanh'}.  ``transposed``: ``weight`` is
     the [in, out, 3, 3] weight of a ConvTranspose2d(k 3, stride 1, padding 1), which is the same convolution with the
     weight transposed and flipped.  ``x`` may be a list of up to four tensors, meaning their concatenation along the
-    channels; the Winograd kernel reads the parts where they lie, every other path concatenates them first."""
+    channels; the Winograd kernel reads the parts where they lie, every other path concatenates them first.
+    ``out``: a contiguous tensor (e.g. a batch slice of a larger buffer) to receive the result; the Winograd paths write it
+    directly, every other path copies into it."""
+    if out is not None:
+        y = _conv_bias_act(x, weight, bias, padding, act, transposed, out)
+        if y is not out:
+            out.copy_(y)
+        return out
+    return _conv_bias_act(x, weight, bias, padding, act, transposed, None)
+
+
+def _conv_bias_act(x, weight, bias, padding, act, transposed, out):
     if isinstance(x, (list, tuple)):
         parts = list(x)
         x0 = parts[0]
@@ -339,10 +356,10 @@ def conv_bias_act(x, weight, bias, padding, act, transposed=False):
                   and not (torch.is_grad_enabled() and (weight.requires_grad or bias.requires_grad or any(p.requires_grad for p in parts)))
                   and _wino_ok(N, Ci, Co, H, W, kh, kw, padding))
         if not direct:
-            return conv_bias_act(torch.cat(parts, dim=1), weight, bias, padding, act, transposed)
+            return _conv_bias_act(torch.cat(parts, dim=1), weight, bias, padding, act, transposed, out)
         L = _native.lib()
         U = _wino_weights(weight, transposed)
-        y = torch.empty((N, Co, H, W), dtype=x0.dtype, device=x0.device)
+        y = out if _usable_out(out, (N, Co, H, W), x0) else torch.empty((N, Co, H, W), dtype=x0.dtype, device=x0.device)
         ptrs = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
         with torch.cuda.device(x0.device):
             _native.check(L.tai_conv3x3_wino_forward_parts(ptrs, len(parts), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci,
@@ -385,7 +402,7 @@ def conv_bias_act(x, weight, bias, padding, act, transposed=False):
         # Winograd F(2x2,3x3) on the fp32 MFMA pipe (csrc/wino_conv.hip.inc)
         x = x.contiguous()
         U = _wino_weights(weight, transposed)
-        y = torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device)
+        y = out if _usable_out(out, (N, Co, H, W), x) else torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device)
         with torch.cuda.device(x.device):
             _native.check(L.tai_conv3x3_wino_forward(x.data_ptr(), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci, Co,
                                                      H, W, _ACT[act], stream), 'tai_conv3x3_wino_forward')

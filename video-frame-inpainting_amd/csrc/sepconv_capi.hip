@@ -477,7 +477,7 @@ int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_s,
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: parts must have equal channel counts, a multiple of 8");
     if (shift_s != 0 && (shift_s < 2 || shift_s > 3 || C % (shift_s * shift_s) != 0 || (C / (shift_s * shift_s)) % 8 != 0))
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: shift_s in {2, 3}, C = shift_s^2 x (a multiple of 8)");
-    if ((addx == nullptr) != (y2 == nullptr)) return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: addx and y2 go together");
+    if (y2 && !addx) return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: y2 needs addx");
     const float* p[4];
     for (int i = 0; i < 4; ++i) {
         p[i] = xs[i < nparts ? i : 0];
@@ -521,7 +521,8 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
     (void)skip;
     const int pmode = S ? 2 : (nparts > 1 ? 1 : 0);
 #define TAI_WINO_ARGS xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, Kpad, nchunks
-#define TAI_WINO_TAIL stamps, pool_h, pool_w, pool_oy, pool_ox, ex.addx, ex.y2, S
+    const int part_magic = S ? (1 << 20) / (cpart / 8) + 1 : 0;     // chunk -> channel block of the displaced reads
+#define TAI_WINO_TAIL stamps, pool_h, pool_w, pool_oy, pool_ox, ex.addx, ex.y2, S, part_magic
 #define TAI_LAUNCH_WINO(A, D, SK, Q)                                                                                     \
     do {                                                                                                               \
         if (tall) {      /* 128-channel x 32-tile workgroups (half the patch transform and LDS writes per MFMA) */    \

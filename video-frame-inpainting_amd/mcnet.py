@@ -138,11 +138,18 @@ class Residual(nn.Module):
     def forward(self, input_dyn, input_cont):
         return _conv_relu_chain((input_dyn, input_cont), self.res.convs(), last_act=None)   # conv(cat(..)) without the cat
 
-    def forward_unpool_add(self, input_dyn, input_cont, below):
-        """(res, res + fixed_unpooling(below)): the block's output and the sum DecCnn forms from it (mcnet.py:234-236)."""
+    def forward_into(self, input_dyn, input_cont, out):
+        """forward() with the result written into ``out`` (a batch slice of a larger buffer): no cat afterwards."""
         c0, c1 = self.res.convs()
         mid = conv_bias_act((input_dyn, input_cont), c0.weight, c0.bias, c0.padding[0], 'relu')
-        return conv_bias_unpool_add(mid, c1.weight, c1.bias, c1.padding[0], below)
+        return conv_bias_act(mid, c1.weight, c1.bias, c1.padding[0], None, out=out)
+
+    def forward_unpool_add(self, input_dyn, input_cont, below, keep_res=True):
+        """(res, res + fixed_unpooling(below)): the block's output and the sum DecCnn forms from it (mcnet.py:234-236);
+        ``keep_res=False`` returns (None, sum)."""
+        c0, c1 = self.res.convs()
+        mid = conv_bias_act((input_dyn, input_cont), c0.weight, c0.bias, c0.padding[0], 'relu')
+        return conv_bias_unpool_add(mid, c1.weight, c1.bias, c1.padding[0], below, keep_plain=keep_res)
 
 
 class DecCnn(nn.Module):
@@ -227,6 +234,10 @@ class MCNet(nn.Module):
         self.residual2 = Residual(gf_dim * 4, gf_dim * 2)
         self.residual1 = Residual(gf_dim * 2, gf_dim * 1)
         self.dec_cnn = DecCnn(c_dim, gf_dim)
+        # res[t][0], the full-resolution residual, is part of what the reference's MCNet.forward returns (mcnet.py:453) but
+        # no model of the path reads it (tai.py:224-226 only reaches indices 2 and 1); a fill-in model that knows this sets
+        # keep_res1 = False and gets None in that slot: the residual then exists only inside the decoder's sum
+        self.keep_res1 = True
 
     def get_initial_conv_lstm_state(self, batch_size, image_size, like):
         return like.new_zeros(batch_size, 8 * self.gf_dim, image_size[0] // 8, image_size[1] // 8)
@@ -257,7 +268,7 @@ class MCNet(nn.Module):
             # unpool(stage below) + residual, the input of its decoder stage
             res_3, u3 = self.residual3.forward_unpool_add(res_m[2], res_c[2], h_tpl)
             res_2, u2 = self.residual2.forward_unpool_add(res_m[1], res_c[1], self.dec_cnn.stage(3, u3))
-            res_1, u1 = self.residual1.forward_unpool_add(res_m[0], res_c[0], self.dec_cnn.stage(2, u2))
+            res_1, u1 = self.residual1.forward_unpool_add(res_m[0], res_c[0], self.dec_cnn.stage(2, u2), keep_res=self.keep_res1)
             res.append([res_1, res_2, res_3])
             x_hat = self.dec_cnn.stage(1, u1)
             x_hat_gray = gray01(x_hat)

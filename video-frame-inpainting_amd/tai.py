@@ -170,8 +170,10 @@ def generate_both_directions(generator, K, Fn, T, diff_in, xt, diff_in_F, xt_F, 
     if fuse and K == Fn:
         B = xt.shape[0]
         pred, dyn, cont, res = generator(K, T, torch.cat([diff_in, diff_in_F], 0), torch.cat([xt, xt_F], 0))
-        fwd = ([p[:B] for p in pred], [d[:B] for d in dyn], [c[:B] for c in cont], [[r[:B] for r in rs] for rs in res])
-        bwd = ([p[B:] for p in pred], [d[B:] for d in dyn], [c[B:] for c in cont], [[r[B:] for r in rs] for rs in res])
+        lo = lambda r: None if r is None else r[:B]        # (res[t][0] is None when the generator drops it: keep_res1)
+        hi = lambda r: None if r is None else r[B:]
+        fwd = ([p[:B] for p in pred], [d[:B] for d in dyn], [c[:B] for c in cont], [[lo(r) for r in rs] for rs in res])
+        bwd = ([p[B:] for p in pred], [d[B:] for d in dyn], [c[B:] for c in cont], [[hi(r) for r in rs] for rs in res])
     else:
         fwd, bwd = generator(K, T, diff_in, xt), generator(Fn, T, diff_in_F, xt_F)
     return fwd, tuple(x[::-1] for x in bwd)
@@ -190,12 +192,14 @@ class TAIFillInModel(nn.Module):
         self.c_dim = c_dim
         self.conv_lstm_state_size = 8 * gf_dim
         self.generator = MCNet(gf_dim, c_dim, feature_size, forget_bias=forget_bias, bias=bias)
+        self.generator.keep_res1 = False      # merge_residual1 is never evaluated (see above): res[t][0] has no reader
         self.merge_residual3 = Residual(gf_dim * 8, kf_dim * 4)
         self.merge_residual2 = Residual(gf_dim * 4, kf_dim * 2)
         self.merge_residual1 = Residual(gf_dim * 2, kf_dim * 1)   # in the checkpoint schema; output never consumed
         self.kernelnet = TAI(gf_dim, ks, num_block, layers, kf_dim)
         self.fuse_directions = True
         self.batch_time_steps = True
+        self.merge_per_step = True
         self._ratio_cache = {}
 
     def _ratio_per_sample(self, T, B, w, device):
@@ -221,8 +225,19 @@ class TAIFillInModel(nn.Module):
             # ONE batch of T*B (time-major), i.e. a fifth of the launches and larger MIOpen problems for the small maps.
             B = preceding_frames.shape[0]
             cat = lambda xs: torch.cat(list(xs), dim=0)
-            merged = {1: self.merge_residual2(cat(r[1] for r in f_res), cat(r[1] for r in b_res)),
-                      2: self.merge_residual3(cat(r[2] for r in f_res), cat(r[2] for r in b_res))}
+            # the merge blocks run per time step (their inputs are the largest tensors of the model: batching them would
+            # mean copying ~1 GB into time-major stacks) and write straight into their slice of the time-major result
+            merged = {}
+            if not self.merge_per_step:
+                merged = {1: self.merge_residual2(cat(r[1] for r in f_res), cat(r[1] for r in b_res)),
+                          2: self.merge_residual3(cat(r[2] for r in f_res), cat(r[2] for r in b_res))}
+            for idx, block in (((1, self.merge_residual2), (2, self.merge_residual3)) if self.merge_per_step else ()):
+                r0 = f_res[0][idx]
+                outc = block.res.convs()[-1].weight.shape[0]
+                buf = r0.new_empty((T * B, outc) + tuple(r0.shape[2:]))
+                for t in range(T):
+                    block.forward_into(f_res[t][idx], b_res[t][idx], buf[t * B:(t + 1) * B])
+                merged[idx] = buf
             ratio = self._ratio_per_sample(T, B, w, preceding_frames.device)
             dot1, dot2 = self.kernelnet(cat(f_pred).contiguous(), cat(b_pred).contiguous(), cat(f_dyn), cat(b_dyn),
                                         cat(f_cont), cat(b_cont), merged, ratio=ratio)
