@@ -93,7 +93,33 @@ def test_flip_and_backwards_augmentation(tmp_path, monkeypatch):
     lst = tmp_path / 'l.txt'
     lst.write_text('%s 1-6\n' % (tmp_path / 'c.npy'))
     ds = vdata.ContiguousVideoClipDataset(3, str(lst), 6, True, True, (8, 8), False, (0, 0))
-    monkeypatch.setattr(vdata.random, 'random', lambda: 0.9)                  # both augmentations on (:66-67)
+    monkeypatch.setattr(ds.rng, 'random', lambda: 0.9)                        # both augmentations on (:66-67)
     x = ds[0]['targets']
     want = torch.from_numpy(fr[::-1, :, ::-1, ::-1].copy()).permute(0, 3, 1, 2).float() / 255 * 2 - 1
     assert torch.allclose(x, want, atol=1e-6)
+
+
+def test_random_draws_are_private_and_reproducible(tmp_path):
+    """Window starts, augmentation flips and replacement lines come from the dataset's own generator: the same seed gives
+    the same clips, and the global random / numpy.random streams (which data-parallel ranks share with nothing) are not
+    touched -- a decode retry on one rank cannot desynchronise anything else."""
+    import random
+    fr = _frames(T=12, H=8, W=8)
+    np.save(tmp_path / 'c.npy', fr)
+    lst = tmp_path / 'l.txt'
+    lst.write_text('%s 1-12\n%s\n%s 3-11\n' % (tmp_path / 'c.npy', tmp_path / 'missing.npy', tmp_path / 'c.npy'))
+    mk = lambda seed: vdata.ContiguousVideoClipDataset(3, str(lst), 5, True, True, (8, 8), True, (0, 0), seed=seed)
+    random.seed(123); np.random.seed(123)
+    g_py, g_np = random.getstate(), np.random.get_state()[1].copy()
+    a, b, c = mk(7), mk(7), mk(8)
+    xa = [a[i]['targets'] for i in (0, 1, 2, 1)]            # index 1 cannot be opened: replaced by a random other line
+    xb = [b[i]['targets'] for i in (0, 1, 2, 1)]
+    xc = [c[i]['targets'] for i in (0, 1, 2, 1)]
+    assert all(torch.equal(p, q) for p, q in zip(xa, xb))
+    assert not all(torch.equal(p, q) for p, q in zip(xa, xc))
+    assert random.getstate() == g_py and np.array_equal(np.random.get_state()[1], g_np)
+    rec = vdata.ClipRecord('/x/vid.avi 3-7 10-12')
+    assert rec.path == '/x/vid.avi' and rec.spans == [(2, 6), (9, 11)] and rec.label(rec.spans) == 'vid.avi_3-7_10-12'
+    assert vdata.ClipRecord('/x/v').spans is None
+    with pytest.raises(RuntimeError):
+        vdata.ClipRecord('/x/v 3_7')

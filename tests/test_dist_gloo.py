@@ -45,6 +45,36 @@ def _worker(rank, world, port, out_dir):
     for i, p in enumerate(disc.parameters()):
         mean = np.mean([gathered[r][i] for r in range(world)], axis=0)
         np.testing.assert_allclose(p.grad.numpy(), mean, rtol=1e-6, atol=1e-7)
+    # the overlapped form: gradients accumulate inside the flat buckets, each bucket's all-reduce is launched from the
+    # backward pass by the hook of its last gradient; one parameter gets no gradient at all (its bucket still travels).
+    # (a plain network: the SN discriminator rescales its weights in every forward, so two passes differ by design)
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Conv2d(1, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1),
+                              torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 3, padding=1))
+    xin = x[:, 0]
+    unused = torch.nn.Parameter(torch.ones(3))
+    reducer2 = parallel.GradAllReducer(list(net.parameters()) + [unused], bucket_bytes=1024)
+    assert len(reducer2.buckets) > 2
+    for step in range(2):                                            # the second step reuses the buckets (views in place)
+        local = torch.autograd.grad(net(xin).pow(2).mean(), list(net.parameters()))
+        gathered2 = [None] * world
+        dist.all_gather_object(gathered2, [g.numpy() for g in local])
+        reducer2.zero_grad()
+        assert all(p.grad is not None and float(p.grad.abs().sum()) == 0 for p in net.parameters())
+        launched = []
+        orig = reducer2._launch
+        reducer2._launch = lambda b, orig=orig: (launched.append(b), orig(b))[1]
+        net(xin).pow(2).mean().backward()
+        assert len(launched) >= len(reducer2.buckets) - 1            # every bucket but (at most) the one holding `unused`
+        reducer2._launch = orig
+        assert reducer2.allreduce_() == sum(p.numel() * 4 for p in net.parameters()) + 12
+        for i, p in enumerate(net.parameters()):
+            mean = np.mean([gathered2[r][i] for r in range(world)], axis=0)
+            np.testing.assert_allclose(p.grad.numpy(), mean, rtol=1e-5, atol=1e-7)
+        assert float(unused.grad.abs().sum()) == 0
+        with torch.no_grad():
+            for p in net.parameters():
+                p.sub_(0.1 * p.grad)
     opt.step()
     flat = torch.cat([p.detach().reshape(-1) for p in disc.parameters()] + [u.reshape(-1) for u in us])
     torch.save(flat, os.path.join(out_dir, 'rank%d.pt' % rank))

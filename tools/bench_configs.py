@@ -12,8 +12,7 @@ from video_frame_inpainting_amd.graph import GraphedForward
 dev = torch.device('cuda:0')
 torch.backends.cudnn.allow_tf32 = False
 for name, key, B, C, H, W, K, T, F in (('cfg4', 'TAI_color', 16, 3, 256, 256, 3, 5, 3), ('cfg5', 'TAI_gray', 32, 1, 128, 128, 5, 10, 5)):
-    torch.manual_seed(0)
-    m = vfi.create_model(key); m.apply(vfi.util.weights_init); m.to(dev).eval()
+    m = synthetic.seeded_init(vfi.create_model(key), 0); m.to(dev).eval()
     clips = synthetic.make_clips(B, K + T + F, C, H, W, synthetic.SEEDS[name])
     P, _, Fo = (torch.from_numpy(x).to(dev) for x in synthetic.split_clip(clips, K, T, F))
     t0 = time.time()

@@ -31,10 +31,11 @@ def main(args=None):
     loader = None
     if getattr(opt, 'train_video_list_path', None) and not opt.synthetic:
         dataset = ContiguousVideoClipDataset(opt.c_dim, opt.train_video_list_path, opt.K + opt.T + opt.F, not opt.no_backwards,
-                                             not opt.no_flip, opt.image_size, True, opt.padding_size)
+                                             not opt.no_flip, opt.image_size, True, opt.padding_size, seed=opt.seed + 7 * rank)
         gen = torch.Generator().manual_seed(opt.seed + 7 * rank)
         loader = torch.utils.data.DataLoader(dataset, batch_size=opt.batch_size, shuffle=not opt.serial_batches,
-                                             num_workers=opt.num_threads, drop_last=True, generator=gen)
+                                             num_workers=opt.num_threads, drop_last=True, generator=gen,
+                                             worker_init_fn=dataset.worker_init)
         print('# training videos = %d' % len(dataset))
 
         def batches():                                               # inf_data_loader (train.py:41)

@@ -95,21 +95,90 @@ def resize_bilinear(frame, height, width):
     return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
 
 
-class ContiguousVideoClipDataset(data.Dataset):
-    """base_dataset.py:17-202: one line per video, ``<path>`` or ``<path> <a>-<b>`` (1-indexed inclusive frame range);
-    an item is a random window of ``seq_length`` consecutive frames of that range."""
+class ClipRecord(object):
+    """One parsed line of a video list.  Formats (reference base_dataset.py:147-156, :214-222), frame numbers 1-indexed and
+    inclusive in the file, 0-indexed here:
+        <path>                      the whole video                      spans = None
+        <path> a-b                  one span                             spans = [(a-1, b-1)]
+        <path> a-b c-d              preceding and following span         spans = [(a-1, b-1), (c-1, d-1)]"""
 
-    def __init__(self, c_dim, video_list_path, seq_length, backwards, flip, image_size, resample_on_fail, padding_size):
+    _SPAN = re.compile(r'^(\d+)-(\d+)$')
+
+    def __init__(self, line):
+        fields = line.split()
+        if not fields:
+            raise RuntimeError('Empty line in video list')
+        self.line = line
+        self.path = fields[0]
+        self.spans = None
+        if len(fields) > 1:
+            matches = [self._SPAN.match(f) for f in fields[1:]]
+            if not all(matches):
+                raise RuntimeError('Cannot parse frame ranges of video-list line "%s"' % line)
+            self.spans = [(int(m.group(1)) - 1, int(m.group(2)) - 1) for m in matches]
+
+    def label(self, spans):
+        """``<basename>_a-b[_c-d]`` with 1-indexed inclusive numbers: the directory name predict.py writes into."""
+        return '_'.join([os.path.basename(self.path)] + ['%d-%d' % (a + 1, b + 1) for a, b in spans])
+
+
+class _ClipReader(object):
+    """Frames of one clip -> the tensor the models take (base_dataset.py:50-103): resize, RGB -> BGR, optional horizontal
+    flip, constant padding on the bottom / right, [-1, 1], gray if c_dim == 1, optional time reversal."""
+
+    def __init__(self, c_dim, image_size, padding_size):
+        self.c_dim, self.image_size, self.padding_size = c_dim, image_size, padding_size
+
+    @staticmethod
+    def frame(source, index):
+        try:
+            return np.asarray(source.get_data(index))
+        except IndexError:
+            raise
+        except Exception as e:                                      # a decoder's read error (:129-137)
+            warn('Failed to read frame %d in %s: %s' % (index, getattr(source, '_filename', '?'), e))
+            return None
+
+    def clip(self, source, indexes, mirror, reverse):
+        frames = []
+        for t in indexes:
+            raw = self.frame(source, t)
+            if raw is None:
+                return None
+            img = resize_bilinear(raw, self.image_size[0], self.image_size[1])[:, :, ::-1]      # RGB -> BGR (:81)
+            if mirror:
+                img = img[:, ::-1, :]
+            # cv2.copyMakeBorder(..., BORDER_CONSTANT, -1) on uint8 saturates the -1 to 0, i.e. -1.0 after the [-1, 1] map
+            img = np.pad(img, ((0, self.padding_size[0]), (0, self.padding_size[1]), (0, 0)), mode='constant')
+            frames.append(torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().div(255))
+        if reverse:
+            frames.reverse()
+        clip = fore_transform(torch.stack(frames))                  # T x C x H x W in [-1, 1]
+        return bgr2gray(clip) if self.c_dim == 1 else clip
+
+
+class ContiguousVideoClipDataset(data.Dataset):
+    """base_dataset.py:17-202: one line per video, ``<path>`` or ``<path> <a>-<b>``; an item is a random window of
+    ``seq_length`` consecutive frames of that range, optionally mirrored / reversed; a video that cannot be opened, is too
+    short or fails to decode is replaced by another random line when ``resample_on_fail`` (else RuntimeError).
+
+    Every random draw (window start, augmentation coin flips, replacement line) comes from a PRIVATE generator seeded per
+    dataset (``seed``; reseeded per DataLoader worker by ``worker_init``): the reference draws from the global ``random``
+    and ``numpy.random`` modules, which in a data-parallel run is also where (K, T, F) used to come from -- one rank's
+    decode retry would desynchronise every rank's model shapes."""
+
+    def __init__(self, c_dim, video_list_path, seq_length, backwards, flip, image_size, resample_on_fail, padding_size,
+                 seed=0):
         super().__init__()
-        self.c_dim = c_dim
-        self.backwards = backwards
-        self.flip = flip
-        self.image_size = image_size
-        self.resample_on_fail = resample_on_fail
-        self.padding_size = padding_size
         with open(video_list_path, 'r') as f:
             self.files = [line.strip() for line in f.readlines()]
         self.seq_len = seq_length
+        self.backwards, self.flip, self.resample_on_fail = backwards, flip, resample_on_fail
+        self.reader = _ClipReader(c_dim, image_size, padding_size)
+        self.rng = random.Random(seed)
+
+    def worker_init(self, worker_id):
+        self.rng = random.Random((self.rng.random(), worker_id))
 
     def __len__(self):
         return len(self.files)
@@ -117,93 +186,52 @@ class ContiguousVideoClipDataset(data.Dataset):
     def open_video(self, vid_path):
         return open_frame_source(vid_path)
 
-    def get_frame(self, vid, frame_index):
-        try:
-            return np.asarray(vid.get_data(frame_index))
-        except IndexError:
-            raise
-        except Exception as e:                                      # a decoder's read error (:129-137)
-            warn('Failed to read frame %d in %s: %s' % (frame_index, getattr(vid, '_filename', '?'), e))
-            return None
-
-    def read_seq(self, vid, frame_indexes, clip_label):
-        """base_dataset.py:50-103."""
-        targets = []
-        flip_flag = self.flip and (random.random() > 0.5)
-        back_flag = self.backwards and (random.random() > 0.5)
-        for t in frame_indexes:
-            frame = self.get_frame(vid, t)
-            if frame is None:
-                return None
-            img = resize_bilinear(frame, self.image_size[0], self.image_size[1])[:, :, ::-1]      # RGB -> BGR (:81)
-            if flip_flag:
-                img = img[:, ::-1, :]
-            # cv2.copyMakeBorder(..., BORDER_CONSTANT, -1) on uint8 saturates the -1 to 0, i.e. -1.0 after the [-1, 1] map
-            img = np.pad(img, ((0, self.padding_size[0]), (0, self.padding_size[1]), (0, 0)), mode='constant')
-            targets.append(torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().div(255))   # to_tensor
-        if back_flag:
-            targets = targets[::-1]
-        target = fore_transform(torch.stack(targets))               # T x C x H x W in [-1, 1]
-        if self.c_dim == 1:
-            target = bgr2gray(target)
-        return {'targets': target, 'clip_label': clip_label}
+    def _try(self, record):
+        """-> (item, None) or (None, reason)."""
+        source = self.open_video(record.path)
+        if source is None:
+            return None, 'Video at %s could not be opened' % record.path
+        first, last = record.spans[0] if record.spans else (0, source.get_length() - 1)
+        if last - first + 1 < self.seq_len:
+            return None, 'Interval %s in video %s is too short' % (str((first, last)), record.path)
+        start = self.rng.randint(first, last - self.seq_len + 1)
+        mirror = self.flip and self.rng.random() > 0.5
+        reverse = self.backwards and self.rng.random() > 0.5
+        clip = self.reader.clip(source, range(start, start + self.seq_len), mirror, reverse)
+        if clip is None:
+            return None, 'Failed to sample frames starting at %d in %s' % (start, record.path)
+        return {'targets': clip, 'clip_label': record.label([(first, last)])}, None
 
     def __getitem__(self, index):
-        while True:
-            split_line = self.files[index].split()
-            if len(split_line) == 1:
-                video_file_path, full_range_str = split_line[0], None
-            else:
-                video_file_path, full_range_str = split_line
-            vid = self.open_video(video_file_path)
-            if vid is None:
-                if not self.resample_on_fail:
-                    raise RuntimeError('Video at %s could not be opened' % video_file_path)
-                index = np.random.randint(0, len(self.files))
-                continue
-            if full_range_str is None:
-                full_range = (0, vid.get_length() - 1)
-            else:
-                full_range = tuple(int(d) - 1 for d in full_range_str.split('-'))      # 0-indexed, inclusive
-            if full_range[1] - full_range[0] + 1 < self.seq_len:
-                if not self.resample_on_fail:
-                    raise RuntimeError('Interval %s in video %s is too short' % (str(full_range), video_file_path))
-                index = np.random.randint(0, len(self.files))
-                continue
-            start_index = random.randint(full_range[0], full_range[1] - self.seq_len + 1)
-            frame_indexes = range(start_index, start_index + self.seq_len)
-            clip_label = '%s_%d-%d' % (os.path.basename(video_file_path), full_range[0] + 1, full_range[1] + 1)
-            item = self.read_seq(vid, frame_indexes, clip_label)
-            if item is None:
-                if not self.resample_on_fail:
-                    raise RuntimeError('Failed to sample frames starting at %d in %s' % (start_index, video_file_path))
-                index = np.random.randint(0, len(self.files))
-                continue
-            return item
+        item, reason = self._try(ClipRecord(self.files[index]))
+        while item is None:
+            if not self.resample_on_fail:
+                raise RuntimeError(reason)
+            item, reason = self._try(ClipRecord(self.files[self.rng.randrange(len(self.files))]))
+        return item
 
 
 class DisjointVideoClipDataset(ContiguousVideoClipDataset):
-    """base_dataset.py:205-248: ``<path> <a>-<b> <c>-<d>``: the preceding frames a..b and the following frames c..d
-    (1-indexed inclusive), nothing in between."""
+    """base_dataset.py:205-248: ``<path> <a>-<b> <c>-<d>``: the preceding frames a..b and the following frames c..d,
+    nothing in between; no augmentation, no resampling."""
 
     def __init__(self, c_dim, video_list_path, K, F, image_size, padding_size):
         super().__init__(c_dim, video_list_path, None, False, False, image_size, False, padding_size)
-        self.K = K
-        self.F = F
+        self.K, self.F = K, F
 
     def __getitem__(self, index):
-        m = re.match(r'(.+) (\d+)-(\d+) (\d+)-(\d+)', self.files[index])
-        if m is None:
+        try:
+            record = ClipRecord(self.files[index])
+        except RuntimeError:
+            record = None
+        if record is None or record.spans is None or len(record.spans) != 2:
             raise RuntimeError('Expected line from video list to have format "<video_path> <A-B> <C-D>", '
                                'but found line "%s")' % self.files[index])
-        video_file_path = m.group(1)
-        p_a, p_b, f_a, f_b = (int(v) - 1 for v in m.group(2, 3, 4, 5))
-        vid = self.open_video(video_file_path)
-        if vid is None:
-            raise RuntimeError('Video at %s could not be opened' % video_file_path)
-        frame_indexes = list(range(p_a, p_b + 1)) + list(range(f_a, f_b + 1))
-        clip_label = '%s_%d-%d_%d-%d' % (os.path.basename(video_file_path), p_a + 1, p_b + 1, f_a + 1, f_b + 1)
-        item = self.read_seq(vid, frame_indexes, clip_label)
-        if item is None:
-            raise RuntimeError('Failed to sample frames %d-%d and %d-%d in %s' % (p_a, p_b, f_a, f_b, video_file_path))
-        return item
+        source = self.open_video(record.path)
+        if source is None:
+            raise RuntimeError('Video at %s could not be opened' % record.path)
+        indexes = [t for a, b in record.spans for t in range(a, b + 1)]
+        clip = self.reader.clip(source, indexes, False, False)
+        if clip is None:
+            raise RuntimeError('Failed to sample frames %s in %s' % (record.label(record.spans), record.path))
+        return {'targets': clip, 'clip_label': record.label(record.spans)}

@@ -174,8 +174,16 @@ class BaseTrainingEnvironment(BaseVideoFillInEnvironment):
         torch.save(self.get_current_state_dict(total_updates, sum_avg_psnr_err, sum_avg_ssim_err),
                    os.path.join(self.save_dir, snapshot_file_name))
 
+    def _zero_grad(self, optimizer, reducer):
+        """One process: the reference's ``optimizer.zero_grad()``.  Data parallel: gradients live in the reducer's flat
+        buckets and each bucket's all-reduce starts during the backward pass (parallel.GradAllReducer)."""
+        if parallel.world_size() > 1:
+            reducer.zero_grad()
+        else:
+            optimizer.zero_grad()
+
     def optimize_parameters(self):
-        self.optimizer_G.zero_grad()
+        self._zero_grad(self.optimizer_G, self._reducer_G)
         self.compute_loss_G()
         self.loss_G.backward()
         self._reducer_G.allreduce_()
@@ -252,7 +260,7 @@ class L2GDLDiscTrainingEnvironment(BaseTrainingEnvironment):
 
     def optimize_parameters(self):
         super().optimize_parameters()
-        self.optimizer_D.zero_grad()
+        self._zero_grad(self.optimizer_D, self._reducer_D)
         self.compute_loss_D()
         self.loss_D.backward()
         self._reducer_D.allreduce_()
