@@ -170,8 +170,9 @@ int tai_conv3x3_wino_timeline_skip(int level);
  *   10-13 = 8-wave workgroups mixing "taps first" (type A) and "taps last" (type B) waves on every SIMD;
  *       13 adds 16-byte patch staging and alternating wave priorities, 16 (default for C == 1) = 13 with each XCD
  *       given a contiguous eighth of the tile list,
- *   14/15 = type-A waves that load their taps once and run the row loop once per channel (8- / 4-wave workgroups;
- *       15 is the default for C > 1).
+ *   14/15 = type-A waves that load their taps once and run the row loop once per channel (8- / 4-wave workgroups),
+ *   17 (default for C > 1) = type-A waves that walk three channel patches per tap row: v and h are read once for all
+ *       three channels (channels beyond a multiple of three run on the single-channel kernel).
  *   Values >= 100 (timing experiments that produce wrong results) exist only in the tools build of the library
  *   (-DTAI_TIMING_VARIANTS, build/libtai_sepconv_timing.so); the shipped library rejects them with TAI_SEPCONV_EINVAL.
  * Returns the previous value. */

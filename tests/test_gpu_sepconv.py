@@ -62,7 +62,7 @@ def test_forward_and_backward_match_oracle(B, C, H, W, ks):
     assert _rel(out.detach().cpu().numpy(), lit.astype(np.float64)) < 2 * FWD_TOL
 
 
-@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
 @pytest.mark.parametrize('C', [1, 3])
 def test_every_forward_variant(variant, C):
     inp, v, h, _ = _case(2, C, 24, 128, 51, 5)

@@ -13,7 +13,7 @@ echo "[5] bench LDS counters"; timeout -k 10 300 rocprofv3 --pmc SQ_LDS_BANK_CON
 echo "[6] sepconv backward"; timeout -k 10 400 tools/prof_bwd.sh r02 > $out/prof_bwd.log 2>&1
 echo "[7] sepconv forward C=3 (cfg4 shape)"
 S="./build/sepconv_bench 16 3 256 256 6"
-export TAI_VARIANTS=15
+export TAI_VARIANTS=17
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c3_trace -- ./build/sepconv_bench 16 3 256 256 30 > $out/c3_trace.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/c3_fetch -- $S > $out/c3_fetch.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/c3_write -- $S > $out/c3_write.log 2>&1

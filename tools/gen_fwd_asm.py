@@ -347,6 +347,117 @@ def gen_gv():
     return L
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Three-channel type-A row loop (RGB frames, configs[3]): the taps are channel-independent, so a lane walks the THREE channel
+# patches per tap row -- 3 x (14 window reads, 100 v_pk_fma_f32 + 4 v_fmac_f32) -- and folds each channel's row sums with the
+# SAME v values: v and h are read from HBM exactly once (the per-channel passes of sepconv_forward_asm_channels re-streamed
+# v: measured traffic 1.94x algorithmic).  LDS: three (16 + 50)-row patches = 141 KB leave 16 KB for the v rings, i.e. two
+# 1 KB slots per wave (one row of v in flight; a tap row lasts 3x as long as in the one-channel loop).
+#   O_c[p] (scalar, not packed: 12 registers instead of 24):  channel 0 v[212:215], channel 1 v[216:219], channel 2 v[236:239];
+#   row window addresses: v248 / v249 / v250 = v240 + c * C3_PATCH_BYTES (the offset does not fit a 16-bit immediate).
+C3_PATCH_BYTES = ((16 + KS - 1) * PITCH_BYTES + 1023) & ~1023
+C3_SLOTS = 2
+C3_V_AT = 4           # chunk of channel 0 behind which the row's v values are read from the ring
+C3_O = lambda c, p: (212, 216, 236)[c] + p
+C3_ROW = lambda c: 248 + c
+
+
+def emit_chunk_read_c3(lines, j, base, next_row):
+    """running chunk j of a row's 42 (channel j // 14, chunk j % 14); next_row: the read belongs to the following tap row."""
+    c, k = divmod(j, NCHUNK)
+    off = (PITCH_BYTES if next_row else 0) + 16 * k
+    b = BUF(base + j)
+    if k == NCHUNK - 1:
+        lines.append('ds_read_b64 v[%d:%d], v%d offset:%d' % (b, b + 1, C3_ROW(c), off))
+    else:
+        lines.append('ds_read_b128 v[%d:%d], v%d offset:%d' % (b, b + 3, C3_ROW(c), off))
+
+
+def emit_row_c3(L, phase):
+    """One tap row.  LDS operations complete in issue order, so the wait that makes operation X visible is lgkmcnt(number of
+    LDS operations issued after X): `queue` mirrors the issue order (the three look-ahead reads of this row's first chunks
+    were issued by the previous row)."""
+    base = 3 * NCHUNK * phase
+    total = 3 * NCHUNK
+    queue = [('chunk', j) for j in range(LOOKAHEAD)]
+
+    def wait_for(op):
+        L.append('s_waitcnt lgkmcnt(%d)' % (len(queue) - 1 - queue.index(op)))
+
+    # DMA of row fy + 1 into the other slot, at once: its occupant (row fy - 1) went to registers a row ago.  Row fy's own
+    # values were requested at the start of row fy - 1 and are read from the ring only at chunk C3_V_AT of channel 0, behind
+    # a vmcnt(1) that leaves the DMA just issued in flight: more than a whole tap row of lead with two slots per wave.
+    L.append('s_add_u32 %s, %s, %s' % (S_T0, S_RINGM0, S_SLOT_WR))
+    L.append('s_mov_b32 m0, %s' % S_T0)
+    L.append('s_nop 0')
+    L.append('global_load_lds_dwordx4 v%d, s[64:65]' % V_GOFF)
+    L.append('s_cmp_lt_u32 %s, %d' % (S_ROW, KS - 2))
+    L.append('s_cselect_b32 %s, %s, 0' % (S_T1, S_PLANE))
+    L.append('s_add_u32 %s, %s, %s' % (S_PTR_LO, S_PTR_LO, S_T1))
+    L.append('s_addc_u32 %s, %s, 0' % (S_PTR_HI, S_PTR_HI))
+    L.append('s_xor_b32 %s, %s, 1024' % (S_SLOT_WR, S_SLOT_WR))
+    for c in range(3):
+        first_done = set()
+        for k in range(NCHUNK):
+            j = c * NCHUNK + k
+            nj = j + LOOKAHEAD
+            if nj < total:
+                emit_chunk_read_c3(L, nj, base, False)
+            else:
+                emit_chunk_read_c3(L, nj - total, base + total, True)
+            queue.append(('chunk', nj))
+            if c == 0 and k == C3_V_AT:
+                L.append('s_waitcnt vmcnt(1)')                             # row fy of v has landed (row fy + 1 may be in flight)
+                L.append('v_add_u32 v%d, %s, v%d' % (V_TMP, S_SLOT_RD, V_RING))
+                L.append('ds_read_b128 v[%d:%d], v%d' % (VV, VV + 3, V_TMP))
+                L.append('s_xor_b32 %s, %s, 1024' % (S_SLOT_RD, S_SLOT_RD))
+                queue.append(('v', 0))
+            wait_for(('chunk', j))
+            # the chunk's FMAs: emit_chunk_fmas indexes buffers by base + k, so pass the channel's running base
+            emit_chunk_fmas(L, k, first_done, base + c * NCHUNK)
+        if c == 0:
+            wait_for(('v', 0))
+        # fold with v:  O_c[p] += v_p * (ACC_p.lo + ACC_p.hi)
+        for pp in range(4):
+            L.append('v_fmac_f32 v%d, v%d, v%d' % (C3_O(c, pp), VV + pp, ACC(pp)))
+            L.append('v_fmac_f32 v%d, v%d, v%d' % (C3_O(c, pp), VV + pp, ACC(pp) + 1))
+    for c in range(3):
+        L.append('v_add_u32 v%d, %d, v%d' % (C3_ROW(c), PITCH_BYTES, C3_ROW(c)))
+    L.append('s_add_u32 %s, %s, 1' % (S_ROW, S_ROW))
+
+
+def gen_c3():
+    L = []
+    for c in range(3):
+        for pp in range(4):
+            L.append('v_mov_b32 v%d, 0' % C3_O(c, pp))
+    L.append('v_mov_b32 v%d, v%d' % (C3_ROW(0), V_ROW_IN))
+    L.append('v_add_u32 v%d, %d, v%d' % (C3_ROW(1), C3_PATCH_BYTES, V_ROW_IN))
+    L.append('v_add_u32 v%d, %d, v%d' % (C3_ROW(2), 2 * C3_PATCH_BYTES, V_ROW_IN))
+    L.append('s_mov_b32 %s, s60' % S_PTR_LO)
+    L.append('s_mov_b32 %s, s61' % S_PTR_HI)
+    L.append('s_mov_b32 m0, %s' % S_RINGM0)                               # row 0 of v into slot 0
+    L.append('s_nop 0')
+    L.append('global_load_lds_dwordx4 v%d, s[64:65]' % V_GOFF)
+    L.append('s_add_u32 %s, %s, %s' % (S_PTR_LO, S_PTR_LO, S_PLANE))
+    L.append('s_addc_u32 %s, %s, 0' % (S_PTR_HI, S_PTR_HI))
+    L.append('s_mov_b32 %s, 0' % S_ROW)
+    L.append('s_mov_b32 %s, 0' % S_SLOT_RD)
+    L.append('s_mov_b32 %s, 1024' % S_SLOT_WR)
+    for j in range(LOOKAHEAD):
+        emit_chunk_read_c3(L, j, 0, False)
+    L.append('.p2align 6')
+    L.append('1:')
+    assert NBUF == 4 and (3 * NCHUNK) % NBUF == 2                            # the buffer rotation repeats every two rows
+    emit_row_c3(L, 0)
+    emit_row_c3(L, 1)
+    L.append('s_cmp_lt_u32 %s, %d' % (S_ROW, KS - 1))
+    L.append('s_cbranch_scc1 1b')
+    emit_row_c3(L, 0)
+    L.append('s_waitcnt vmcnt(0) lgkmcnt(0)')
+    return L
+
+
 def main():
     global LOOKAHEAD, NBUF, ABLATE_VMCNT, ABLATE_LGKM, PRIO_ALTERNATE
     here = os.path.dirname(os.path.abspath(__file__))
@@ -383,6 +494,17 @@ def main():
         for l in lines:
             f.write('    "%s\\n" \\\n' % l)
         f.write('    ""\n')
+        lines = gen_c3()
+        n_pk = sum(1 for l in lines if l.startswith('v_pk_'))
+        f.write('// TAI_FWD_ROWLOOP_C3_ASM (three channel patches per tap row, v read once): %d instructions, %d packed.\n' % (len(lines), n_pk))
+        f.write('#define TAI_FWD_ROWLOOP_C3_PATCH_BYTES %d\n#define TAI_FWD_ROWLOOP_C3_RING_SLOTS %d\n' % (C3_PATCH_BYTES, C3_SLOTS))
+        f.write('#define TAI_FWD_ROWLOOP_C3_ASM \\\n')
+        for l in lines:
+            f.write('    "%s\\n" \\\n' % l)
+        f.write('    ""\n')
+        clob_c3 = ['v%d' % r for r in list(range(204, 212)) + list(range(220, 236)) + [243, 244, 245, 246, 247, 248, 249, 250]]
+        clob_c3 += ['s%d' % r for r in range(64, 71)] + ['scc', 'memory']
+        f.write('#define TAI_FWD_ROWLOOP_C3_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob_c3))
         clob_gv = ['v%d' % r for r in list(range(204, 212)) + list(range(220, 240)) + [248]]
         clob_gv += ['s%d' % r for r in (64, 65, 66, 74, 75)] + ['scc', 'memory']
         f.write('#define TAI_GV_ROWLOOP_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob_gv))

@@ -151,6 +151,28 @@ int fwd_asm_channel_loop(const float* in, const float* v, const float* h, float*
     return check_launch("sepconv_forward_asm_channels");
 }
 
+// channels in groups of three through the three-patch row loop; what is left over through the per-channel loop
+int fwd_asm_three_channels(const float* in, const float* v, const float* h, float* out, int B, int C, int H, int W, hipStream_t s) {
+    const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W, tiles_y = (H + 15) / 16;
+    const size_t lds = (size_t)3 * TAI_FWD_ROWLOOP_C3_PATCH_BYTES + (size_t)8 * TAI_FWD_ROWLOOP_C3_RING_SLOTS * 1024;
+    auto kern = fwd::sepconv_forward_asm_c3;
+    if (int rc = allow_lds(kern, lds)) return rc;
+    int c0 = 0;
+    for (; c0 + 3 <= C; c0 += 3) {
+        hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(512), lds, s, in, v, h, out, C, c0, H, W, tiles_x, tiles_y);
+        if (int rc = check_launch("sepconv_forward_asm_c3")) return rc;
+    }
+    for (; c0 < C; ++c0) {
+        const size_t patch = (size_t)(16 + 50) * 180 * sizeof(float);
+        const size_t lds1 = ((patch + 1023) & ~(size_t)1023) + (size_t)8 * TAI_FWD_ROWLOOP_RING_SLOTS * 1024;
+        auto k1 = fwd::sepconv_forward_ab<4, 0>;
+        if (int rc = allow_lds(k1, lds1)) return rc;
+        hipLaunchKernelGGL(k1, dim3(B * tiles_x * tiles_y), dim3(512), lds1, s, in, v, h, out, C, c0, H, W, tiles_x, tiles_y);
+        if (int rc = check_launch("sepconv_forward_ab")) return rc;
+    }
+    return TAI_SEPCONV_OK;
+}
+
 template <int KS>
 int fwd_packed_all_channels(const float* in, const float* v, const float* h, float* out, int B, int C,
                             int H, int W, hipStream_t s) {
@@ -212,7 +234,7 @@ int tai_sepconv_set_grad_input_variant(int variant) { return g_gi_variant.exchan
 
 int tai_sepconv_default_forward_variant(int C, int W, int ks) {
     const bool tileable = (ks == 51) && (W % 4 == 0);
-    return !tileable ? 1 : (C == 1 ? 16 : 15);
+    return !tileable ? 1 : (C == 1 ? 16 : 17);
 }
 
 long long tai_sepconv_forward_bytes(int B, int C, int H, int W, int ks) {
@@ -234,7 +256,7 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
 
     int variant = g_fwd_variant.load(std::memory_order_relaxed);
     const bool tileable = (ks == 51) && (W % 4 == 0);
-    // default: mixed type-A / type-B hand-scheduled kernel for single-channel frames; taps-once channel loop otherwise
+    // default: mixed type-A / type-B hand-scheduled kernel for single-channel frames; three channel patches per tap row otherwise
     if (variant == 0) variant = tai_sepconv_default_forward_variant(C, W, ks);
     if (variant != 1 && !tileable)
         return fail(TAI_SEPCONV_EINVAL, "%s", "tiled forward variants need ks == 51 and W % 4 == 0");
@@ -260,6 +282,7 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 16: return fwd_ab_all_channels<4>(input, vertical, horizontal, output, B, C, H, W, s);
         case 14: return fwd_asm_channel_loop<8>(input, vertical, horizontal, output, B, C, H, W, s);
         case 15: return fwd_asm_channel_loop<4>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 17: return fwd_asm_three_channels(input, vertical, horizontal, output, B, C, H, W, s);
 #ifdef TAI_TIMING_VARIANTS   // timing experiments (wrong results by design): tools/ build only, never in the shipped library
         case 108: return fwd_ab_all_channels<3, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 106: return fwd_ab_all_channels<0, 3>(input, vertical, horizontal, output, B, C, H, W, s);
