@@ -340,8 +340,9 @@ def test_general_entry_point_rejects_bad_arguments():
     def call(**kw):
         a = dict(ok, **kw)
         return L.tai_conv3x3_wino_forward_ex(xs, a['nparts'], a['shift'], p, p, p, None, 0, 0, 0, 0, None, None, a['N'], a['C'], a['K'],
-                                             a['H'], a['W'], a['in_h'], a['in_w'], a['in_oy'], a['in_ox'], 0, s)
+                                             a['H'], a['W'], a['in_h'], a['in_w'], a['in_oy'], a['in_ox'], a.get('act', 1), s)
     assert call() == 0
+    assert call(act=0) == -1                                             # displaced reads are built with ReLU only
     assert call(shift=4) == -1 and call(C=4 * 6) == -1                   # shift_s in {2, 3}; C / shift_s^2 a multiple of 8
     assert call(in_h=12) == -1 and call(in_w=14) == -1 and call(in_ox=0) == -1      # the plane must hold the halo
     assert L.tai_conv3x3_wino_forward_ex(xs, 1, 0, p, p, p, None, 0, 0, 0, 0, None, p, 1, 8, 8, 8, 8, 8, 8, 0, 0, 0, s) == -1   # y2 without addx

@@ -34,7 +34,7 @@ def _kernel_bodies(asm, mangled_prefix):
 @pytest.mark.parametrize('parts', [0, 1])
 def test_counted_waits_match_the_loads_behind_the_last_dma(device_asm, parts, tall, dmas):
     # conv3x3<ACT 1, DBG 0, SKIP 0, PARTS parts, TALL tall> (64 x 64 and 128 x 32 workgroups): the instantiations the product launches
-    prefix = '_ZN4wino7conv3x3ILi1ELi0ELi0ELi%dELb%dE' % (parts, tall)
+    prefix = '_ZN4wino7conv3x3ILi1ELi0ELi0ELi%dELb%dELi0EE' % (parts, tall)
     found = 0
     for name, lines in _kernel_bodies(device_asm, prefix):
         found += 1

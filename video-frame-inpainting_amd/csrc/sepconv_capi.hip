@@ -546,38 +546,47 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
 #define TAI_WINO_ARGS xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, Kpad, nchunks
     const int part_magic = S ? (1 << 20) / (cpart / 8) + 1 : 0;     // chunk -> channel block of the displaced reads
 #define TAI_WINO_TAIL stamps, pool_h, pool_w, pool_oy, pool_ox, ex.addx, ex.y2, S, part_magic
-#define TAI_LAUNCH_WINO(A, D, SK, Q)                                                                                     \
+#define TAI_LAUNCH_WINO(A, D, SK, Q, E)                                                                                  \
     do {                                                                                                               \
         if (tall) {      /* 128-channel x 32-tile workgroups (half the patch transform and LDS writes per MFMA) */    \
             const long long ttb = (tiles + wino::TTN - 1) / wino::TTN;                                                 \
             const int tkb = Kpad / wino::TTM;                                                                          \
-            if (int rc = allow_lds(wino::conv3x3<A, D, SK, Q, true>, wino::TLDS_BYTES)) return rc;                     \
-            hipLaunchKernelGGL((wino::conv3x3<A, D, SK, Q, true>), dim3((unsigned)(ttb * tkb)), dim3(256), wino::TLDS_BYTES, s, \
+            if (int rc = allow_lds(wino::conv3x3<A, D, SK, Q, true, E>, wino::TLDS_BYTES)) return rc;                  \
+            hipLaunchKernelGGL((wino::conv3x3<A, D, SK, Q, true, E>), dim3((unsigned)(ttb * tkb)), dim3(256), wino::TLDS_BYTES, s, \
                                TAI_WINO_ARGS, tkb, TAI_WINO_TAIL);                                                     \
         } else {                                                                                                       \
-            if (int rc = allow_lds(wino::conv3x3<A, D, SK, Q, false>, wino::LDS_BYTES)) return rc;                     \
-            hipLaunchKernelGGL((wino::conv3x3<A, D, SK, Q, false>), dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::LDS_BYTES, s, \
+            if (int rc = allow_lds(wino::conv3x3<A, D, SK, Q, false, E>, wino::LDS_BYTES)) return rc;                  \
+            hipLaunchKernelGGL((wino::conv3x3<A, D, SK, Q, false, E>), dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::LDS_BYTES, s, \
                                TAI_WINO_ARGS, kblocks, TAI_WINO_TAIL);                                                 \
         }                                                                                                              \
     } while (0)
 #define TAI_LAUNCH_WINO_ACT(D, SK, Q)                                   \
     do {                                                                \
-        if (act == 0) TAI_LAUNCH_WINO(0, D, SK, Q);                     \
-        else if (act == 1) TAI_LAUNCH_WINO(1, D, SK, Q);                \
-        else TAI_LAUNCH_WINO(2, D, SK, Q);                              \
+        if (act == 0) TAI_LAUNCH_WINO(0, D, SK, Q, 0);                  \
+        else if (act == 1) TAI_LAUNCH_WINO(1, D, SK, Q, 0);             \
+        else TAI_LAUNCH_WINO(2, D, SK, Q, 0);                           \
     } while (0)
+    // the instantiations the path uses: the second-output / sum epilogues come without activation (Residual's last
+    // convolution) on one tensor or cat operands; the displaced reads come with ReLU (MotionEnc)
+    const int epi = ex.addx ? (ex.y2 ? 1 : 2) : 0;
+    if (epi && (act != 0 || pmode == 2 || stamps)) return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: addx needs act 0 and no displaced reads");
+    if (pmode == 2 && act != 1) return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: displaced reads are built for act 1 (ReLU)");
     if (stamps) {        // timeline launches (tools/wino_timeline.py): ReLU, one tensor
 #ifdef TAI_TIMING_VARIANTS
-        if (skip == 1) TAI_LAUNCH_WINO(1, 1, 1, 0);
-        else if (skip == 2) TAI_LAUNCH_WINO(1, 1, 2, 0);
-        else if (skip == 4) TAI_LAUNCH_WINO(1, 1, 4, 0);
-        else if (skip == 5) TAI_LAUNCH_WINO(1, 1, 5, 0);
-        else if (skip == 7) TAI_LAUNCH_WINO(1, 2, 0, 0);
+        if (skip == 1) TAI_LAUNCH_WINO(1, 1, 1, 0, 0);
+        else if (skip == 2) TAI_LAUNCH_WINO(1, 1, 2, 0, 0);
+        else if (skip == 4) TAI_LAUNCH_WINO(1, 1, 4, 0, 0);
+        else if (skip == 5) TAI_LAUNCH_WINO(1, 1, 5, 0, 0);
+        else if (skip == 7) TAI_LAUNCH_WINO(1, 2, 0, 0, 0);
         else
 #endif
-        TAI_LAUNCH_WINO(1, 1, 0, 0);
+        TAI_LAUNCH_WINO(1, 1, 0, 0, 0);
     }
-    else if (pmode == 2) TAI_LAUNCH_WINO_ACT(0, 0, 2);
+    else if (epi == 1 && pmode == 1) TAI_LAUNCH_WINO(0, 0, 0, 1, 1);
+    else if (epi == 1) TAI_LAUNCH_WINO(0, 0, 0, 0, 1);
+    else if (epi == 2 && pmode == 1) TAI_LAUNCH_WINO(0, 0, 0, 1, 2);
+    else if (epi == 2) TAI_LAUNCH_WINO(0, 0, 0, 0, 2);
+    else if (pmode == 2) TAI_LAUNCH_WINO(1, 0, 0, 2, 0);
     else if (pmode == 1) TAI_LAUNCH_WINO_ACT(0, 0, 1);
     else TAI_LAUNCH_WINO_ACT(0, 0, 0);
 #undef TAI_LAUNCH_WINO_ACT
