@@ -1,0 +1,16 @@
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+import video_frame_inpainting_amd as vfi
+from video_frame_inpainting_amd import synthetic, conv_ops
+dev='cuda:0'
+m = synthetic.seeded_init(vfi.create_model('TAI_gray'), 0).to(dev).eval()
+clips = synthetic.make_clips(32, 15, 1, 128, 128, 1002)
+P,_,Fo = (torch.from_numpy(x).to(dev) for x in synthetic.split_clip(clips,5,5,5))
+orig = F.conv2d
+seen = {}
+def logged(x, w, *a, **k):
+    key=(tuple(x.shape), tuple(w.shape)); seen[key]=seen.get(key,0)+1
+    return orig(x, w, *a, **k)
+conv_ops.F.conv2d = logged
+with torch.no_grad(): m(5,P,Fo)
+for k,v in seen.items(): print(k, v)

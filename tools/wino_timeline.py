@@ -26,8 +26,9 @@ for level in levels:
             nch = min((C + 7) // 8, 26)
             pro = t[:, 1] - t[:, 0]; loop = t[:, 2] - t[:, 1]; epi = t[:, 3] - t[:, 2]; tot = t[:, 3] - t[:, 0]
             ch = np.diff(np.concatenate([t[:, 1:2], t[:, 4:4 + nch]], axis=1), axis=1)
-            print('x(%d,%d,%d,%d)->%d [%s]: %d workgroups, %d chunks; clocks: prologue %.0f  loop %.0f (%.0f/chunk; ideal 4096)  epilogue %.0f  total %.0f'
-                  % (N, C, H, W, K, '128 x 32' if tall else '64 x 64', wgs, (C + 7) // 8, np.median(pro), np.median(loop), np.median(loop) / max((C + 7) // 8, 1), np.median(epi), np.median(tot)))
+            ghz = np.median(tot / np.maximum(t[:, 61] - t[:, 60], 1)) * 0.1      # shader cycles per 100 MHz tick
+            print('x(%d,%d,%d,%d)->%d [%s]: %d workgroups, %d chunks; clocks: prologue %.0f  loop %.0f (%.0f/chunk; ideal 4096)  epilogue %.0f  total %.0f  shader clock %.2f GHz'
+                  % (N, C, H, W, K, '128 x 32' if tall else '64 x 64', wgs, (C + 7) // 8, np.median(pro), np.median(loop), np.median(loop) / max((C + 7) // 8, 1), np.median(epi), np.median(tot), ghz))
             print('   per-chunk median by index:', ' '.join('%.0f' % v for v in np.median(ch, axis=0)[:16]), ' p90 of all chunks %.0f' % np.percentile(ch, 90), flush=True)
 L.tai_conv3x3_wino_timeline_skip(0)
 L.tai_conv3x3_wino_set_tall(1)
