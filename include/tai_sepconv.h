@@ -187,7 +187,7 @@ int tai_sepconv_default_forward_variant(int C, int W, int ks);
  *       any other shape: the bounds-checked gather;
  *   1 = bounds-checked gather of the reference (any shape, bit-reproducible, ~40x slower);
  *   2 = round-1 kernel: LDS row-scatter with a barrier per tap row and float atomics (last bits depend on arrival order);
- *   3 = as 0 (explicit).
+ *   3 = as 0 (explicit);  4 = as 0 with the row loop in HIP C++ instead of the generated assembly (A/B).
  * Returns the previous value. */
 int tai_sepconv_set_grad_input_variant(int variant);
 

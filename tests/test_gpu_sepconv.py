@@ -146,12 +146,13 @@ def _grad_input(inp, v, h, gO, variant, taps_too=True):
 
 @pytest.mark.parametrize('B,C,H,W', [(2, 3, 20, 132), (2, 1, 33, 128), (1, 1, 128, 128), (1, 3, 7, 260)])
 def test_all_grad_input_kernels_match_oracle(B, C, H, W):
-    # 0 / 3: wave-private strips + fixed-order slab sum (default when tileable); 1: the reference-style gather; 2: the
-    # round-1 LDS row-scatter with atomics.  All against the fp64 oracle, and against each other.
+    # 0 / 3: wave-private strips (row loop in generated assembly) + fixed-order slab sum (default when tileable); 4: the same
+    # with the HIP C++ row loop; 1: the reference-style gather; 2: the round-1 LDS row-scatter with atomics.  All against the
+    # fp64 oracle, and against each other.
     inp, v, h, gO = _case(B, C, H, W, 51, 12)
     rI, _, _ = so.backward(gO.numpy(), inp.numpy(), v.numpy(), h.numpy(), 51, f64=True)
     got = {}
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 1, 2, 3, 4):
         got[variant] = _grad_input(inp, v, h, gO, variant).cpu().numpy()
         assert _rel(got[variant], rI) < BWD_TOL, variant
     assert np.array_equal(got[0], got[3])

@@ -458,6 +458,156 @@ def gen_c3():
     return L
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# grad_input row loop (csrc/sepconv_bwd.hip.inc, sepconv_grad_i_strips_asm): the forward's type-A inner product with
+#   * the taps = SHEARED products S'_p[t] = (gO h[50-t])[y, X_p - (50 - t)], X_p = 4q - 2 + p, in the same register order
+#     (v[51p + t]), so that out_p = sum_t S'_p[t] * w[p + t] over the window w = v[fy][y, 4q - 52 ...] -- exactly the forward's
+#     pairing (emit_chunk_fmas is shared);
+#   * the "patch" = the row of the v plane of this tap row, in a workgroup-shared ring of 9 plane slots filled by LDS-DMA
+#     three planes (one stage) at a time, two stages ahead; one s_barrier per stage;
+#   * the four row sums added into the wave-private accumulator strip (ds_read_b128 at the start of the step, add,
+#     ds_write_b128 behind the owner mask), 96 bytes further per tap row.
+# Inputs: v240 window address in plane slot 0; v241 accumulator address of tap row 0; v242 lane * 16 (DMA offset);
+#   s[60:61] &v[b, 0, row w] (DMA source of this wave's first ring row), s62 plane bytes, s63 LDS address of that row in slot 0,
+#   s[72:73] DMA lane mask, s[74:75] owner lane mask, s[78:79] != 0: the wave also copies ring row w + 8 from there (the pointer
+#   stays as given: the loop advances its own copy), s77 its LDS address in slot 0.
+GI_PLANE_BYTES = (64 + 10 * 152 + 64) * 4       # gi2::PLANE floats
+GI_SLOTS = 9
+GI_ACC_STEP = 6 * 16                              # one accumulator row of a strip: Q quads x 16 bytes
+GI_T = 236                                        # v[236:239]: the accumulator row being updated
+GI_WIN, GI_WIN_NEXT, GI_ACCA = 248, 249, 250      # window address of this / the next tap row, accumulator address
+S_SLOT_N, S_DSLOT = 's67', 's68'                  # slot byte offsets: the next tap row's, the DMA's
+S_P2LO, S_P2HI = 's80', 's81'
+
+
+def emit_gi_dma_stage(L):
+    """LDS-DMA of the three planes of one stage into slots S_DSLOT, +1, +2 (this wave's ring rows)."""
+    L.append('s_mov_b64 s[82:83], exec')
+    L.append('s_mov_b64 exec, s[72:73]')
+    for k in range(3):
+        L.append('s_add_u32 %s, %s, %s' % (S_T0, S_RINGM0, S_DSLOT))
+        L.append('s_mov_b32 m0, %s' % S_T0)
+        L.append('s_nop 0')
+        L.append('global_load_lds_dwordx4 v%d, s[64:65]' % V_GOFF)
+        L.append('s_add_u32 %s, %s, %s' % (S_PTR_LO, S_PTR_LO, S_PLANE))
+        L.append('s_addc_u32 %s, %s, 0' % (S_PTR_HI, S_PTR_HI))
+        L.append('s_cmp_eq_u64 s[78:79], 0')
+        L.append('s_cbranch_scc1 2f')
+        L.append('s_add_u32 %s, s77, %s' % (S_T0, S_DSLOT))
+        L.append('s_mov_b32 m0, %s' % S_T0)
+        L.append('s_nop 0')
+        L.append('global_load_lds_dwordx4 v%d, s[80:81]' % V_GOFF)
+        L.append('s_add_u32 %s, %s, %s' % (S_P2LO, S_P2LO, S_PLANE))
+        L.append('s_addc_u32 %s, %s, 0' % (S_P2HI, S_P2HI))
+        L.append('2:')
+        L.append('s_add_u32 %s, %s, %d' % (S_DSLOT, S_DSLOT, GI_PLANE_BYTES))
+        L.append('s_cmp_eq_u32 %s, %d' % (S_DSLOT, GI_SLOTS * GI_PLANE_BYTES))
+        L.append('s_cselect_b32 %s, 0, %s' % (S_DSLOT, S_DSLOT))
+    L.append('s_mov_b64 exec, s[82:83]')
+
+
+def emit_gi_chunk_read(lines, k, next_row, base):
+    b = BUF(base + k)
+    reg = GI_WIN_NEXT if next_row else GI_WIN
+    if k == NCHUNK - 1:
+        lines.append('ds_read_b64 v[%d:%d], v%d offset:%d' % (b, b + 1, reg, 16 * k))
+    else:
+        lines.append('ds_read_b128 v[%d:%d], v%d offset:%d' % (b, b + 3, reg, 16 * k))
+
+
+def emit_row_gi(L, phase, step_in_stage, final_stage=False):
+    """One tap row.  step_in_stage 0: the stage's first row (barrier first; reads nothing ahead of it); 2: its last row (does
+    not read ahead into the next stage: those planes are only known to have landed behind the next barrier)."""
+    base = NCHUNK * phase
+    queue = []
+
+    def wait_for(op):
+        L.append('s_waitcnt lgkmcnt(%d)' % (len(queue) - 1 - queue.index(op)))
+
+    if step_in_stage == 0:
+        # stage boundary: this wave's rows of the stage have landed (the next stage may be in flight), everyone's have, and
+        # the stage before it has been consumed by every wave: its slots take the DMA of two stages ahead
+        if final_stage:
+            L.append('s_waitcnt vmcnt(0)')
+        else:
+            L.append('s_cmp_eq_u64 s[78:79], 0')
+            L.append('s_cbranch_scc1 3f')
+            L.append('s_waitcnt vmcnt(6)')
+            L.append('s_branch 4f')
+            L.append('3:')
+            L.append('s_waitcnt vmcnt(3)')
+            L.append('4:')
+        L.append('s_barrier')
+        if not final_stage:
+            L.append('s_cmp_lt_u32 %s, %d' % (S_ROW, KS - 6))             # tap rows fy + 6 .. fy + 8 exist
+            L.append('s_cbranch_scc0 5f')
+            emit_gi_dma_stage(L)
+            L.append('5:')
+        for k in range(LOOKAHEAD):                                         # nothing was read ahead across the barrier
+            emit_gi_chunk_read(L, k, False, base)
+            queue.append(('chunk', k))
+    else:
+        queue = [('chunk', k) for k in range(LOOKAHEAD)]                  # issued by the previous tap row
+    # the accumulator row of this tap row: read now, used after the last chunk
+    L.append('ds_read_b128 v[%d:%d], v%d' % (GI_T, GI_T + 3, GI_ACCA))
+    queue.append(('acc', 0))
+    # window address of the next tap row (its first chunks are read ahead from here)
+    L.append('v_add_u32 v%d, %s, v%d' % (GI_WIN_NEXT, S_SLOT_N, V_ROW_IN))
+    first_done = set()
+    for k in range(NCHUNK):
+        nk = k + LOOKAHEAD
+        if nk < NCHUNK:
+            emit_gi_chunk_read(L, nk, False, base)
+            queue.append(('chunk', nk))
+        elif step_in_stage != 2:
+            emit_gi_chunk_read(L, nk - NCHUNK, True, base + NCHUNK)
+            queue.append(('next', nk - NCHUNK))
+        wait_for(('chunk', k))
+        emit_chunk_fmas(L, k, first_done, base)
+    wait_for(('acc', 0))
+    for pp in range(4):
+        L.append('v_add_f32 v%d, v%d, v%d' % (ACC(pp), ACC(pp), ACC(pp) + 1))
+    for pp in range(4):
+        L.append('v_add_f32 v%d, v%d, v%d' % (GI_T + pp, GI_T + pp, ACC(pp)))
+    L.append('s_mov_b64 s[82:83], exec')
+    L.append('s_mov_b64 exec, s[74:75]')
+    L.append('ds_write_b128 v%d, v[%d:%d]' % (GI_ACCA, GI_T, GI_T + 3))
+    L.append('s_mov_b64 exec, s[82:83]')
+    L.append('v_add_u32 v%d, %d, v%d' % (GI_ACCA, GI_ACC_STEP, GI_ACCA))
+    L.append('v_mov_b32 v%d, v%d' % (GI_WIN, GI_WIN_NEXT))
+    # slot offset of the tap row after the next
+    L.append('s_add_u32 %s, %s, %d' % (S_SLOT_N, S_SLOT_N, GI_PLANE_BYTES))
+    L.append('s_cmp_eq_u32 %s, %d' % (S_SLOT_N, GI_SLOTS * GI_PLANE_BYTES))
+    L.append('s_cselect_b32 %s, 0, %s' % (S_SLOT_N, S_SLOT_N))
+    L.append('s_add_u32 %s, %s, 1' % (S_ROW, S_ROW))
+
+
+def gen_gi():
+    L = []
+    L.append('s_mov_b32 %s, s60' % S_PTR_LO)
+    L.append('s_mov_b32 %s, s61' % S_PTR_HI)
+    L.append('s_mov_b32 %s, s78' % S_P2LO)
+    L.append('s_mov_b32 %s, s79' % S_P2HI)
+    L.append('s_mov_b32 %s, 0' % S_DSLOT)
+    emit_gi_dma_stage(L)                                                   # stages 0 and 1: tap rows 0 .. 5
+    emit_gi_dma_stage(L)
+    L.append('s_mov_b32 %s, 0' % S_ROW)
+    L.append('s_mov_b32 %s, %d' % (S_SLOT_N, GI_PLANE_BYTES))              # slot offset of tap row 1
+    L.append('v_mov_b32 v%d, v%d' % (GI_WIN, V_ROW_IN))
+    L.append('v_mov_b32 v%d, v%d' % (GI_ACCA, V_RING))
+    L.append('.p2align 6')
+    L.append('1:')
+    # window buffers rotate with period 2 tap rows, stages with period 3: the loop body is 6 tap rows, 51 = 8 x 6 + 3
+    for i in range(6):
+        emit_row_gi(L, i % 2, i % 3)
+    L.append('s_cmp_lt_u32 %s, %d' % (S_ROW, 48))
+    L.append('s_cbranch_scc1 1b')
+    for i in range(3):
+        emit_row_gi(L, i % 2, i % 3, final_stage=True)
+    L.append('s_waitcnt vmcnt(0) lgkmcnt(0)')
+    return L
+
+
 def main():
     global LOOKAHEAD, NBUF, ABLATE_VMCNT, ABLATE_LGKM, PRIO_ALTERNATE
     here = os.path.dirname(os.path.abspath(__file__))
@@ -505,6 +655,15 @@ def main():
         clob_c3 = ['v%d' % r for r in list(range(204, 212)) + list(range(220, 236)) + [243, 244, 245, 246, 247, 248, 249, 250]]
         clob_c3 += ['s%d' % r for r in range(64, 71)] + ['scc', 'memory']
         f.write('#define TAI_FWD_ROWLOOP_C3_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob_c3))
+        lines = gen_gi()
+        f.write('// TAI_GI_ROWLOOP_ASM (grad_input strips: sheared taps x v-plane window, accumulate into the strip): %d instructions.\n' % len(lines))
+        f.write('#define TAI_GI_ROWLOOP_ASM \\\n')
+        for l in lines:
+            f.write('    "%s\\n" \\\n' % l)
+        f.write('    ""\n')
+        clob_gi = ['v%d' % r for r in list(range(204, 212)) + list(range(220, 240)) + [248, 249, 250]]
+        clob_gi += ['s%d' % r for r in (64, 65, 66, 67, 68, 69, 70, 80, 81, 82, 83)] + ['scc', 'memory']
+        f.write('#define TAI_GI_ROWLOOP_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob_gi))
         clob_gv = ['v%d' % r for r in list(range(204, 212)) + list(range(220, 240)) + [248]]
         clob_gv += ['s%d' % r for r in (64, 65, 66, 74, 75)] + ['scc', 'memory']
         f.write('#define TAI_GV_ROWLOOP_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob_gv))

@@ -44,7 +44,7 @@ def timed(gi, gv, gh, per_graph=20, replays=5):
 
 taps = timed(None, gV, gH)
 print('[%d,%d,%d,%d] tap gradients (gV + gH): %.1f us' % (B, C, H, W, taps))
-for variant, name in ((0, 'strips + slab sum (default)'), (2, 'round-1 row scatter + atomics'), (1, 'gather')):
+for variant, name in ((0, 'strips, assembly row loop + slab sum (default)'), (4, 'strips, HIP C++ row loop + slab sum'), (2, 'round-1 row scatter + atomics'), (1, 'gather')):
     if variant == 1 and B * C * H * W > 2 ** 19:
         continue
     prev = L.tai_sepconv_set_grad_input_variant(variant)

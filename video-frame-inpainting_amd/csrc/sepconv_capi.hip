@@ -635,7 +635,7 @@ int tai_sepconv_backward(const float* grad_output, const float* input, const flo
     const bool tileable = (ks == 51) && (W % 4 == 0) && (C == 1 || C == 3);
     const int gi_variant = g_gi_variant.load(std::memory_order_relaxed);
     bool gi_done = false;
-    if (grad_input && tileable && (gi_variant == 0 || gi_variant == 3)) {
+    if (grad_input && tileable && (gi_variant == 0 || gi_variant == 3 || gi_variant == 4)) {
         // gI FIRST (the reference launches V, H, I -- SeparableConvolution_kernel.cu:201-239 -- but the three are
         // independent): wave-private accumulation strips; the tile slabs go to the caller's grad_vertical (or
         // grad_horizontal) buffer, which is filled only afterwards, and a second kernel sums them in a fixed order.
@@ -650,20 +650,24 @@ int tai_sepconv_backward(const float* grad_output, const float* input, const flo
             const size_t bytes = (size_t)B * C * (H + ks - 1) * (W + ks - 1) * sizeof(float);
             if (hipMemsetAsync(grad_input, 0, bytes, s) != hipSuccess) return fail(TAI_SEPCONV_ELAUNCH, "%s", "hipMemsetAsync(gI)");
         }
-        if (C == 1) {
-            auto kern = bwd::sepconv_grad_i_strips<1>;
-            if (int rc = allow_lds(kern, lds)) return rc;
-            hipLaunchKernelGGL(kern, grid, block, lds, s, grad_output, vertical, horizontal, dst, H, W, tiles_x, tiles_y, scratch ? 1 : 0);
-        } else {
-            auto kern = bwd::sepconv_grad_i_strips<3>;
-            if (int rc = allow_lds(kern, lds)) return rc;
-            hipLaunchKernelGGL(kern, grid, block, lds, s, grad_output, vertical, horizontal, dst, H, W, tiles_x, tiles_y, scratch ? 1 : 0);
-        }
+        const bool use_asm = gi_variant != 4;                  // 4: the HIP C++ row loop (A/B)
+        const int to_scratch = scratch ? 1 : 0;
+#define TAI_LAUNCH_GI(KERN)                                                                                                  \
+    do {                                                                                                                   \
+        auto kern = KERN;                                                                                                  \
+        if (int rc = allow_lds(kern, lds)) return rc;                                                                      \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, grad_output, vertical, horizontal, dst, H, W, tiles_x, tiles_y, to_scratch); \
+    } while (0)
+        if (C == 1 && use_asm) TAI_LAUNCH_GI(bwd::sepconv_grad_i_strips_asm<1>);
+        else if (C == 1) TAI_LAUNCH_GI(bwd::sepconv_grad_i_strips<1>);
+        else if (use_asm) TAI_LAUNCH_GI(bwd::sepconv_grad_i_strips_asm<3>);
+        else TAI_LAUNCH_GI(bwd::sepconv_grad_i_strips<3>);
+#undef TAI_LAUNCH_GI
         if (int rc = check_launch("sepconv_grad_i_strips")) return rc;
         if (scratch) {
             const int n = B * C * (H + ks - 1) * ((W + ks - 1) / 2);
             hipLaunchKernelGGL(bwd::sepconv_grad_i_reduce, dim3((n + 255) / 256), dim3(256), 0, s, scratch, grad_input, n, C, H, W,
-                               tiles_x, tiles_y);
+                               tiles_x, tiles_y, use_asm ? 2 : 0);
             if (int rc = check_launch("sepconv_grad_i_reduce")) return rc;
         }
         gi_done = true;
