@@ -42,7 +42,7 @@ def test_cin1_matches_conv2d(k, act, shape):
 
 
 @pytest.mark.parametrize('act', [None, 'relu', 'tanh'])
-@pytest.mark.parametrize('shape', [(2, 64, 32, 32), (3, 16, 20, 36), (1, 64, 128, 128)])
+@pytest.mark.parametrize('shape', [(2, 64, 32, 32), (3, 16, 20, 36), (1, 64, 128, 128), (2, 16, 9, 96), (1, 17, 5, 4)])
 def test_cout1_matches_conv2d(act, shape):
     from video_frame_inpainting_amd.conv_ops import conv_bias_act
     N, Ci, H, W = shape
