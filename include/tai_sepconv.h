@@ -89,7 +89,7 @@ int tai_conv_cin1_forward(const float* x, const float* weight, const float* bias
 int tai_conv_cin1_forward_maxpool(const float* x, const float* weight, const float* bias, float* y, float* ypool, int N, int Co,
                                   int H, int W, int k, int act, void* hip_stream);
 /* ... with ypool written into a plane of pool_h x pool_w whose origin is at (pool_oy, pool_ox):
- * the halo-carrying input plane of the next layer (tai_conv3x3_wino_forward_ex, shift_s), halo left untouched. */
+ * the halo-carrying input plane of the next layer (tai_conv3x3_wino_forward_ex, shift_k), halo left untouched. */
 int tai_conv_cin1_forward_maxpool_window(const float* x, const float* weight, const float* bias, float* y, float* ypool, int N,
                                          int Co, int H, int W, int k, int act, int pool_h, int pool_w, int pool_oy, int pool_ox,
                                          void* hip_stream);
@@ -131,21 +131,24 @@ int tai_conv3x3_wino_forward_window(const float* x, const float* U, const float*
 int tai_conv3x3_wino_forward_parts(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N,
                                    int C, int K, int H, int W, int act, void* hip_stream);
 /* The general form of the same convolution (every optional argument may be NULL / 0):
- *   xs, nparts      1..4 input parts as above; or ONE tensor with shift_s in {2, 3}: the input [N, C / shift_s^2, in_h, in_w]
- *                   is read shift_s x shift_s times, channel block (a, b) = block a * shift_s + b displaced by (3a, 3b)
- *                   pixels.  With the k x k weight cut into shift_s x shift_s blocks of 3 x 3 taps ([K, shift_s^2 * Cin, 3, 3],
- *                   zero past k) this is the k x k "same" convolution of MotionEnc (nn.Conv2d(gf, 2gf, 5, padding=2),
- *                   nn.Conv2d(2gf, 4gf, 7, padding=3): src/models/mcnet/mcnet.py:36-38, 45-47) read from the pooled
- *                   output of the layer before it where it lies -- no stack of shifted copies.  The plane must carry the
- *                   halo: image row 0 at row k/2, so in_oy = 1; image column 0 at column in_ox + k/2 - 1 with in_ox even
- *                   and >= 2; in_h >= H + in_oy + 1 + 3 (shift_s - 1), in_w >= W + in_ox + 2 + 3 (shift_s - 1), halo zero.
+ *   xs, nparts      1..4 input parts as above; or ONE tensor with shift_k = k, the size of a k x k filter (4 <= k <= 9):
+ *                   with S = (k + 2) / 3 the input [N, C / S^2, in_h, in_w] is read S x S times, channel block (a, b) =
+ *                   block a * S + b displaced by (3a, 3b) pixels, and the weight is the k x k filter cut into S x S blocks
+ *                   of 3 x 3 taps, ZERO PAST k ([K, S^2 * Cin, 3, 3]).  This is the k x k "same" convolution of MotionEnc
+ *                   (nn.Conv2d(gf, 2gf, 5, padding=2), nn.Conv2d(2gf, 4gf, 7, padding=3): src/models/mcnet/mcnet.py:36-38,
+ *                   45-47) read from the pooled output of the layer before it where it lies -- no stack of shifted copies.
+ *                   When k is not a multiple of 3 the last block row / column has an all-zero third tap row / column, hence
+ *                   an all-zero fourth row / column of transformed weights: those multiply-adds are skipped (16 % of a
+ *                   7 x 7 layer's, 23 % of a 5 x 5 layer's).  The plane must carry the halo: image row 0 at row k/2, so
+ *                   in_oy = 1; image column 0 at column in_ox + k/2 - 1 with in_ox even and >= 2;
+ *                   in_h >= H + in_oy + 1 + 3 (S - 1), in_w >= W + in_ox + 2 + 3 (S - 1), halo zero.
  *   ypool, pool_*   2x2 max pool of the activated output written into a plane of pool_h x pool_w with its origin at
  *                   (pool_oy, pool_ox) (pool_h = 0: a plain [N, K, H/2, W/2] tensor);
  *   addx, y2        y2 [N, K, H, W] = y + fixed_unpooling(addx), addx [N, K, H/2, W/2] landing on the even (2i, 2j) sites:
  *                   DecCnn's unpool + residual add (src/models/mcnet/mcnet.py:234-236, 240-256) as a second output of the
  *                   Residual block's last convolution (mcnet.py:172-176).  With addx and y2 == NULL the sum is written to y
  *                   (the plain convolution output is then not produced). */
-int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_s, const float* U, const float* bias, float* y,
+int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_k, const float* U, const float* bias, float* y,
                                 float* ypool, int pool_h, int pool_w, int pool_oy, int pool_ox, const float* addx, float* y2, int N,
                                 int C, int K, int H, int W, int in_h, int in_w, int in_oy, int in_ox, int act, void* hip_stream);
 /* Benchmarking: 0 keeps every layer on the 64-channel x 64-tile workgroup shape; 1 (default) lets layers whose K is a

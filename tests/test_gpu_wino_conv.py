@@ -335,7 +335,7 @@ def test_general_entry_point_rejects_bad_arguments():
     p = t.data_ptr()
     xs = (ctypes.c_void_p * 1)(p)
     s = torch.cuda.current_stream().cuda_stream
-    ok = dict(nparts=1, shift=2, N=1, C=4 * 8, K=8, H=8, W=8, in_h=13, in_w=16, in_oy=1, in_ox=2)
+    ok = dict(nparts=1, shift=5, N=1, C=4 * 8, K=8, H=8, W=8, in_h=13, in_w=16, in_oy=1, in_ox=2)
 
     def call(**kw):
         a = dict(ok, **kw)
@@ -343,7 +343,7 @@ def test_general_entry_point_rejects_bad_arguments():
                                              a['H'], a['W'], a['in_h'], a['in_w'], a['in_oy'], a['in_ox'], a.get('act', 1), s)
     assert call() == 0
     assert call(act=0) == -1                                             # displaced reads are built with ReLU only
-    assert call(shift=4) == -1 and call(C=4 * 6) == -1                   # shift_s in {2, 3}; C / shift_s^2 a multiple of 8
+    assert call(shift=3) == -1 and call(shift=10) == -1 and call(C=4 * 6) == -1     # 4 <= shift_k <= 9; C / S^2 a multiple of 8
     assert call(in_h=12) == -1 and call(in_w=14) == -1 and call(in_ox=0) == -1      # the plane must hold the halo
     assert L.tai_conv3x3_wino_forward_ex(xs, 1, 0, p, p, p, None, 0, 0, 0, 0, None, p, 1, 8, 8, 8, 8, 8, 8, 0, 0, 0, s) == -1   # y2 without addx
     torch.cuda.synchronize()

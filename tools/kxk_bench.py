@@ -30,7 +30,7 @@ for (N, Ci, Co, H, W, k) in ((64, 64, 128, 64, 64, 5), (64, 128, 256, 32, 32, 7)
     yp = torch.empty(N, Co, H // 2, W // 2, device=dev)
     xs = (ctypes.c_void_p * 1)(plane.data_ptr())
     s = torch.cuda.current_stream().cuda_stream
-    t_disp = timed(lambda: _native.check(L.tai_conv3x3_wino_forward_ex(xs, 1, S, U.data_ptr(), b.data_ptr(), y.data_ptr(), yp.data_ptr(), 0, 0, 0, 0,
+    t_disp = timed(lambda: _native.check(L.tai_conv3x3_wino_forward_ex(xs, 1, k, U.data_ptr(), b.data_ptr(), y.data_ptr(), yp.data_ptr(), 0, 0, 0, 0,
                                                                       None, None, N, S * S * Ci, Co, H, W, ih, iw, 1, 2, 1, s), 'ex'))
     ya = y.clone()
     t_stack = timed(lambda: conv_ops._kxk_as_wino(x, w, b, 'relu', True))

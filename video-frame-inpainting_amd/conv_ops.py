@@ -188,10 +188,10 @@ def motion_enc_chain(diff, conv1, conv2, conv3):
         _native.check(L.tai_conv_cin1_forward_maxpool_window(diff.data_ptr(), ws[0].contiguous().data_ptr(), bs[0].data_ptr(),
                                                             c1.data_ptr(), plane2.data_ptr(), N, g, H, W, 5, 1, ih2, iw2, top2, left2,
                                                             stream), 'tai_conv_cin1_forward_maxpool_window')
-        _native.check(L.tai_conv3x3_wino_forward_ex(xs2, 1, S2, U2.data_ptr(), bs[1].data_ptr(), c2.data_ptr(), plane3.data_ptr(),
+        _native.check(L.tai_conv3x3_wino_forward_ex(xs2, 1, 5, U2.data_ptr(), bs[1].data_ptr(), c2.data_ptr(), plane3.data_ptr(),
                                                    ih3, iw3, top3, left3, None, None, N, S2 * S2 * g, 2 * g, H2, W2, ih2, iw2, 1, 2, 1,
                                                    stream), 'tai_conv3x3_wino_forward_ex')
-        _native.check(L.tai_conv3x3_wino_forward_ex(xs3, 1, S3, U3.data_ptr(), bs[2].data_ptr(), c3.data_ptr(), p3.data_ptr(),
+        _native.check(L.tai_conv3x3_wino_forward_ex(xs3, 1, 7, U3.data_ptr(), bs[2].data_ptr(), c3.data_ptr(), p3.data_ptr(),
                                                    0, 0, 0, 0, None, None, N, S3 * S3 * 2 * g, 4 * g, H4, W4, ih3, iw3, 1, 2, 1,
                                                    stream), 'tai_conv3x3_wino_forward_ex')
     return p3, [c1, c2, c3]

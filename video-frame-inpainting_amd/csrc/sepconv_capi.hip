@@ -432,6 +432,7 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
 
 struct WinoExtras {                       // optional arguments of the general entry point (tai_conv3x3_wino_forward_ex)
     int shift_s = 0;                      // > 0: ONE input tensor read shift_s x shift_s times, displaced by (3a, 3b)
+    int zero_tail = 0;                    // the k x k filter's last block has an all-zero third tap row / column (k % 3 != 0)
     int pool_h = 0, pool_w = 0, pool_oy = 0, pool_ox = 0;     // ypool plane and origin (0: H/2 x W/2 at (0, 0))
     const float* addx = nullptr;          // y2 = y + fixed_unpooling(addx)
     float* y2 = nullptr;
@@ -491,15 +492,18 @@ int tai_conv3x3_wino_forward_timeline(const float* x, const float* U, const floa
     return wino_forward_impl(xs, 1, U, bias, y, N, C, K, H, W, 1, hip_stream, stamps);
 }
 
-int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_s, const float* U, const float* bias, float* y,
+int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_k, const float* U, const float* bias, float* y,
                                 float* ypool, int pool_h, int pool_w, int pool_oy, int pool_ox, const float* addx, float* y2, int N,
                                 int C, int K, int H, int W, int in_h, int in_w, int in_oy, int in_ox, int act, void* hip_stream) {
-    if (!xs || nparts < 1 || nparts > 4 || (shift_s != 0 && nparts != 1))
-        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: 1 to 4 input parts, or one tensor read shift_s x shift_s times");
+    if (!xs || nparts < 1 || nparts > 4 || (shift_k != 0 && nparts != 1))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: 1 to 4 input parts, or one tensor read S x S times (shift_k)");
+    if (shift_k != 0 && (shift_k < 4 || shift_k > 9))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: shift_k is the size k of the k x k filter, 4 <= k <= 9");
+    const int shift_s = shift_k ? (shift_k + 2) / 3 : 0;
     if (nparts > 1 && (C % nparts != 0 || (C / nparts) % 8 != 0))
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino: parts must have equal channel counts, a multiple of 8");
-    if (shift_s != 0 && (shift_s < 2 || shift_s > 3 || C % (shift_s * shift_s) != 0 || (C / (shift_s * shift_s)) % 8 != 0))
-        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: shift_s in {2, 3}, C = shift_s^2 x (a multiple of 8)");
+    if (shift_s != 0 && (C % (shift_s * shift_s) != 0 || (C / (shift_s * shift_s)) % 8 != 0))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: C = S^2 x (a multiple of 8), S = (shift_k + 2) / 3");
     if (y2 && !addx) return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_ex: y2 needs addx");
     const float* p[4];
     for (int i = 0; i < 4; ++i) {
@@ -507,7 +511,7 @@ int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_s,
         if (!p[i]) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
     }
     WinoExtras ex;
-    ex.shift_s = shift_s; ex.pool_h = pool_h; ex.pool_w = pool_w; ex.pool_oy = pool_oy; ex.pool_ox = pool_ox; ex.addx = addx; ex.y2 = y2;
+    ex.shift_s = shift_s; ex.zero_tail = (shift_k && 3 * shift_s > shift_k) ? 1 : 0; ex.pool_h = pool_h; ex.pool_w = pool_w; ex.pool_oy = pool_oy; ex.pool_ox = pool_ox; ex.addx = addx; ex.y2 = y2;
     return wino_forward_impl(p, nparts, U, bias, y, N, C, K, H, W, act, hip_stream, nullptr, ypool, in_h, in_w, in_oy, in_ox, ex);
 }
 
@@ -545,7 +549,7 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
     const int pmode = S ? 2 : (nparts > 1 ? 1 : 0);
 #define TAI_WINO_ARGS xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, Kpad, nchunks
     const int part_magic = S ? (1 << 20) / (cpart / 8) + 1 : 0;     // chunk -> channel block of the displaced reads
-#define TAI_WINO_TAIL stamps, pool_h, pool_w, pool_oy, pool_ox, ex.addx, ex.y2, S, part_magic
+#define TAI_WINO_TAIL stamps, pool_h, pool_w, pool_oy, pool_ox, ex.addx, ex.y2, S, part_magic, ex.zero_tail
 #define TAI_LAUNCH_WINO(A, D, SK, Q, E)                                                                                  \
     do {                                                                                                               \
         if (tall) {      /* 128-channel x 32-tile workgroups (half the patch transform and LDS writes per MFMA) */    \
