@@ -492,6 +492,10 @@ int tai_conv3x3_wino_forward_timeline(const float* x, const float* U, const floa
     return wino_forward_impl(xs, 1, U, bias, y, N, C, K, H, W, 1, hip_stream, stamps);
 }
 
+#ifdef TAI_TIMING_VARIANTS
+static long long* g_wino_ex_stamps = nullptr;
+int tai_conv3x3_wino_ex_timeline_target(long long* stamps) { g_wino_ex_stamps = stamps; return 0; }
+#endif
 int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_k, const float* U, const float* bias, float* y,
                                 float* ypool, int pool_h, int pool_w, int pool_oy, int pool_ox, const float* addx, float* y2, int N,
                                 int C, int K, int H, int W, int in_h, int in_w, int in_oy, int in_ox, int act, void* hip_stream) {
@@ -511,6 +515,14 @@ int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_k,
         if (!p[i]) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
     }
     WinoExtras ex;
+#ifdef TAI_TIMING_VARIANTS
+    if (g_wino_ex_stamps && shift_s) {     // tools build: the next displaced-read launch writes timeline stamps (ReLU kernels only)
+        ex.shift_s = shift_s; ex.zero_tail = (3 * shift_s > shift_k) ? 1 : 0;
+        long long* st = g_wino_ex_stamps;
+        g_wino_ex_stamps = nullptr;
+        return wino_forward_impl(p, nparts, U, bias, y, N, C, K, H, W, act, hip_stream, st, nullptr, in_h, in_w, in_oy, in_ox, ex);
+    }
+#endif
     ex.shift_s = shift_s; ex.zero_tail = (shift_k && 3 * shift_s > shift_k) ? 1 : 0; ex.pool_h = pool_h; ex.pool_w = pool_w; ex.pool_oy = pool_oy; ex.pool_ox = pool_ox; ex.addx = addx; ex.y2 = y2;
     return wino_forward_impl(p, nparts, U, bias, y, N, C, K, H, W, act, hip_stream, nullptr, ypool, in_h, in_w, in_oy, in_ox, ex);
 }
@@ -582,6 +594,10 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
         else if (skip == 4) TAI_LAUNCH_WINO(1, 1, 4, 0, 0);
         else if (skip == 5) TAI_LAUNCH_WINO(1, 1, 5, 0, 0);
         else if (skip == 7) TAI_LAUNCH_WINO(1, 2, 0, 0, 0);
+        else
+#endif
+#ifdef TAI_TIMING_VARIANTS
+        if (pmode == 2) TAI_LAUNCH_WINO(1, 1, 0, 2, 0);
         else
 #endif
         TAI_LAUNCH_WINO(1, 1, 0, 0, 0);
