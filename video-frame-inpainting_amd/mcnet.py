@@ -192,14 +192,24 @@ class ConvLstmCell(nn.Module):
         self.forget_bias = forget_bias
         self.conv = nn.Conv2d(num_features * 2, num_features * 4, feature_size, padding=(feature_size - 1) // 2, bias=bias)
 
-    def forward(self, input, state):
+    def forward(self, input, state, state_is_zero=False):
         """``state`` is the reference's cat(c, h) tensor or a (c, h) pair; returns (new_h, state) with ``state`` in the
         form it came in.  MCNet.forward keeps the pair: no cat / chunk copies, and conv(cat(input, h)) reads its two
-        operands in place."""
+        operands in place.  ``state_is_zero``: the caller knows h == 0 (the first step of a sequence, mcnet.py:378-388), so
+        the h half of the reduction -- half the convolution -- contributes exact zeros and is left out."""
         as_pair = isinstance(state, (tuple, list))
         c, h = state if as_pair else torch.chunk(state, 2, dim=1)
+        if state_is_zero and not (torch.is_grad_enabled() and self.conv.weight.requires_grad):
+            from .conv_ops import _cached
+            F_ = self.num_features
+            w_in = _cached(self.conv.weight, ('input_half', F_), lambda: self.conv.weight.detach()[:, :F_].contiguous())
+            gates = conv_bias_act(input, w_in, self.conv.bias, self.conv.padding[0], None)
+            return self._gates(gates, c, as_pair)
         x = (input, h) if (as_pair or h.is_contiguous()) else torch.cat((input, h), dim=1)
         gates = conv_bias_act(x, self.conv.weight, self.conv.bias, self.conv.padding[0], None)
+        return self._gates(gates, c, as_pair)
+
+    def _gates(self, gates, c, as_pair):
         N, F4, H, W = gates.shape
         fused = (gates.is_cuda and gates.dtype == torch.float32 and (H * W) % 4 == 0 and c.dtype == torch.float32
                  and not (torch.is_grad_enabled() and (gates.requires_grad or c.requires_grad)))
@@ -252,7 +262,7 @@ class MCNet(nn.Module):
         h_dyn = res_m = None
         for t in range(K - 1):
             enc_h, res_m = self.motion_enc(diffs[t])
-            h_dyn, state = self.conv_lstm_cell(enc_h, state)
+            h_dyn, state = self.conv_lstm_cell(enc_h, state, state_is_zero=(t == 0))
         pred, dyn, cont, res = [], [], [], []
         xt_gray = gray01(xt)
         for t in range(T):
