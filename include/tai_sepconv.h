@@ -105,6 +105,14 @@ int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float*
  * 45-47).  W % 4 == 0. */
 int tai_conv_shift_stack(const float* x, float* out, int N, int C, int H, int W, int k, void* hip_stream);
 
+/* Spectral normalisation of one discriminator layer, as the reference's SNConv2d / SNLinear do on every forward
+ * (src/discriminators/SNDiscriminator.py:10-25 max_singular_value, :60-68 and :84-92 W.data <- W.data / sigma):
+ * Ip rounds of  v <- normalise(u W), u <- normalise(v W^T)  on weight [out_rows, in_cols] (the layer's weight viewed as a
+ * matrix, fp32 contiguous), sigma = (v W^T) u^T, then weight /= sigma IN PLACE and u [out_rows] replaced by the new
+ * vector.  scratch: at least in_cols + out_rows + 1 floats of device memory; the last one receives sigma.  2 Ip + 1
+ * kernel launches on hip_stream, nothing synchronises. */
+int tai_sn_power_iteration(float* weight, float* u, float* scratch, int out_rows, int in_cols, int Ip, void* hip_stream);
+
 /* 3x3 stride-1 zero-padded ("same") convolution + bias + activation, fp32 NCHW contiguous, H and W even, computed as
  * Winograd F(2x2,3x3) on the fp32 MFMA pipe.  Replaces nn.Conv2d(C, K, 3, padding=1) [+ ReLU] of the generator and the
  * kernel network (src/models/mcnet/mcnet.py:79-118,131-152,165-170,271; src/models/tai/tai.py:248-286) and, after the

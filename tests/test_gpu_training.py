@@ -106,3 +106,56 @@ def test_training_step_full_width(tmp_path):
 def test_training_step_short_context_nonsquare(tmp_path):
     """sample_KTF draws K, F >= 2 and T >= 1 per step (environments.py:417-427): K != F (no direction fusion), T = 2."""
     _step_and_compare(tmp_path, gf_dim=8, kf_dim=4, df_dim=8, B=2, K=4, T=2, F=3, H=64, W=96)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape, Ip', [((64, 3, 4, 4), 3), ((128, 64, 4, 4), 3), ((512, 256, 4, 4), 3), ((1, 32768), 1),
+                                       ((37, 5, 3, 3), 2)])
+def test_spectral_norm_kernels_match_the_oracle_power_iteration(shape, Ip):
+    """tai_sn_power_iteration (2 Ip + 1 launches) against the reference's matmul form restated in oracle/train_oracle.py:
+    three consecutive renormalisations (the effect is cumulative and u persists), fp32 tolerance of a few ulps."""
+    from video_frame_inpainting_amd.sn_discriminator import SNConv2d, SNLinear
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    layer = (SNLinear(shape[1], shape[0], Ip=Ip) if len(shape) == 2 else SNConv2d(shape[1], shape[0], shape[2], Ip=Ip)).to(dev)
+    w0 = torch.randn(shape, generator=g) * 0.05
+    u0 = torch.randn(1, shape[0], generator=g)
+    with torch.no_grad():
+        layer.weight.copy_(w0)
+    layer.u = u0.to(dev)
+    ref_w, ref_u = w0.double(), u0.double()
+    for call in range(3):
+        out = layer._renormalise_()
+        sigma, ref_u = train_oracle.max_singular_value(ref_w.view(shape[0], -1), ref_u, Ip)
+        ref_w = ref_w / sigma
+        assert out.data_ptr() != layer.weight.data_ptr() and out.requires_grad       # a value of the moment, not the parameter
+        np.testing.assert_allclose(float(layer.last_sigma), float(sigma), rtol=2e-6)
+        np.testing.assert_allclose(layer.weight.detach().cpu().numpy(), ref_w.float().numpy(), rtol=5e-6, atol=1e-9)
+        np.testing.assert_allclose(layer.u.cpu().numpy(), ref_u.float().numpy(), rtol=0, atol=2e-6)
+        assert torch.equal(out.detach(), layer.weight.detach())
+    # a second layer from the same state ends in the same bits (fixed summation order)
+    layer2 = (SNLinear(shape[1], shape[0], Ip=Ip) if len(shape) == 2 else SNConv2d(shape[1], shape[0], shape[2], Ip=Ip)).to(dev)
+    with torch.no_grad():
+        layer2.weight.copy_(w0)
+    layer2.u = u0.to(dev)
+    for call in range(3):
+        layer2._renormalise_()
+    assert torch.equal(layer2.weight, layer.weight) and torch.equal(layer2.u, layer.u)
+
+
+@pytest.mark.gpu
+def test_sn_linear_single_logit_matches_linear():
+    from video_frame_inpainting_amd.sn_discriminator import SNLinear
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    layer = SNLinear(4096, 1).to(dev)
+    x = torch.randn(6, 4096, device=dev, requires_grad=True)
+    y = layer(x)
+    w = layer.weight.detach().clone()
+    assert y.shape == (6, 1)
+    ref = torch.nn.functional.linear(x.detach().double(), w.double(), layer.bias.detach().double())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    y.sum().backward()
+    np.testing.assert_allclose(layer.weight.grad.cpu().numpy(), x.detach().sum(0, keepdim=True).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), w.expand(6, -1).cpu().numpy(), rtol=1e-6)
+    assert float(layer.bias.grad) == 6.0

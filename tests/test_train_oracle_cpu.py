@@ -48,7 +48,7 @@ def test_discriminator_state_matches_module_over_two_forwards_and_gradients():
     for k, g in zip(bias, grads[len(state.uses):]):
         acc[k] = g
     for k, p in disc.named_parameters():
-        np.testing.assert_allclose(p.grad.numpy(), acc[k].numpy(), rtol=1e-4, atol=1e-7 * float(acc[k].abs().max()) + 1e-12, err_msg=k)
+        np.testing.assert_allclose(p.grad.numpy(), acc[k].numpy(), rtol=1e-4, atol=1e-6 * float(acc[k].abs().max()) + 1e-12, err_msg=k)    # product: mv + vector_norm, oracle: the reference's matmul form
         np.testing.assert_allclose(p.detach().numpy(), state.sd[k].numpy(), rtol=1e-5, atol=1e-7, err_msg=k)   # 3 x 5 renormalisations
     for name, m in disc.named_modules():
         if hasattr(m, 'Ip'):

@@ -32,4 +32,4 @@ if len(sys.argv) > 3:
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
         step(); torch.cuda.synchronize()
-    print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=18, max_name_column_width=70))
+    print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=int(os.environ.get('TAI_PROF_ROWS', '18')), max_name_column_width=90))

@@ -19,6 +19,7 @@
 #include "bias_act.hip.inc"
 #include "thin_conv.hip.inc"
 #include "wino_conv.hip.inc"
+#include "spectral_norm.hip.inc"
 
 namespace {
 
@@ -384,6 +385,29 @@ int tai_convlstm_gates_forward(const float* gates, const float* c, float* new_c,
     hipLaunchKernelGGL(bact::convlstm_gates, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), gates, c, new_c,
                        new_h, N, F, HW / 4, forget_bias);
     return check_launch("convlstm_gates");
+}
+
+int tai_sn_power_iteration(float* weight, float* u, float* scratch, int out_rows, int in_cols, int Ip, void* hip_stream) {
+    g_err[0] = 0;
+    if (!weight || !u || !scratch) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (out_rows <= 0 || in_cols <= 0 || Ip <= 0 || Ip > 64) return fail(TAI_SEPCONV_EINVAL, "%s", "sn_power_iteration: bad shape or Ip");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    float* v_raw = scratch;
+    float* t_raw = scratch + in_cols;
+    float* sigma = t_raw + out_rows;
+    const dim3 wt_block(snorm::WT_COLS, snorm::WT_ROWGROUPS);
+    const int wt_grid = (in_cols + snorm::WT_COLS - 1) / snorm::WT_COLS;
+    for (int it = 0; it < Ip; ++it) {
+        // the stored u is used as it is (SNDiscriminator.py:20-22); later rounds consume the unnormalised product t_raw
+        hipLaunchKernelGGL(snorm::wt_u, dim3(wt_grid), wt_block, 0, stream, weight, it == 0 ? u : t_raw, v_raw, out_rows, in_cols,
+                           it == 0 ? 0 : 1);
+        hipLaunchKernelGGL(snorm::w_v, dim3(out_rows), dim3(256), 0, stream, weight, v_raw, t_raw, in_cols);
+    }
+    const long long n = (long long)out_rows * in_cols;
+    const long long want = (n / 4 + 255) / 256;
+    const int blocks = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+    hipLaunchKernelGGL(snorm::finish, dim3(blocks), dim3(256), 0, stream, weight, t_raw, u, sigma, out_rows, n);
+    return check_launch("sn_power_iteration");
 }
 
 int tai_conv_shift_stack(const float* x, float* out, int N, int C, int H, int W, int k, void* hip_stream) {
