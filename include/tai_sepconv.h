@@ -105,6 +105,16 @@ int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float*
  * 45-47).  W % 4 == 0. */
 int tai_conv_shift_stack(const float* x, float* out, int N, int C, int H, int W, int k, void* hip_stream);
 
+/* Weight gradient of the 3x3 stride-1 padding-1 convolution y = conv(x, w) (the reference's nn.Conv2d / ConvTranspose2d
+ * 3x3 layers under loss.backward(), src/environments/environments.py:348-355), in the Winograd domain on the fp32 MFMA pipe:
+ *   dw [K, C, 3, 3] = sum over n, y, x of dy[n, k, y, x] * x[n, c, y + a - 1, x + b - 1]      (zero padding)
+ * x [N, C, H, W], dy [N, K, H, W] fp32 contiguous, H even, W % 16 == 0, each tensor below 2 GiB.  workspace: device memory
+ * of tai_conv3x3_wino_wrw_workspace_floats(...) floats (-1: shape not supported), overwritten.  Partial sums of the
+ * workgroups are combined in a fixed order: the result is reproducible from call to call. */
+long long tai_conv3x3_wino_wrw_workspace_floats(int N, int C, int K, int H, int W);
+int tai_conv3x3_wino_wrw(const float* x, const float* dy, float* dw, float* workspace, int N, int C, int K, int H, int W,
+                         void* hip_stream);
+
 /* Spectral normalisation of one discriminator layer, as the reference's SNConv2d / SNLinear do on every forward
  * (src/discriminators/SNDiscriminator.py:10-25 max_singular_value, :60-68 and :84-92 W.data <- W.data / sigma):
  * Ip rounds of  v <- normalise(u W), u <- normalise(v W^T)  on weight [out_rows, in_cols] (the layer's weight viewed as a

@@ -347,3 +347,74 @@ def test_general_entry_point_rejects_bad_arguments():
     assert call(in_h=12) == -1 and call(in_w=14) == -1 and call(in_ox=0) == -1      # the plane must hold the halo
     assert L.tai_conv3x3_wino_forward_ex(xs, 1, 0, p, p, p, None, 0, 0, 0, 0, None, p, 1, 8, 8, 8, 8, 8, 8, 0, 0, 0, s) == -1   # y2 without addx
     torch.cuda.synchronize()
+
+
+# ---- Winograd-domain weight gradient (csrc/wino_wrw.hip.inc): dL/dw of nn.Conv2d(C, K, 3, padding=1) under loss.backward()
+# (N, C, K, H, W): channel counts that are not multiples of 8 / 16 / 64, several 64-blocks, one chunk per split, many
+# chunks per split, tile rows of exactly one chunk (W = 16), the bi-TAI shapes
+WRW_SHAPES = [(1, 8, 8, 2, 16), (2, 16, 16, 8, 16), (3, 20, 51, 12, 32), (1, 65, 64, 16, 16), (5, 13, 70, 6, 48), (7, 9, 3, 4, 16),
+              (2, 64, 64, 128, 128), (4, 512, 128, 16, 16), (3, 128, 130, 32, 32), (32, 64, 64, 64, 64)]
+
+
+def _weight_grad_fp64(x, go):
+    xd = x.double()
+    wd = torch.zeros(go.shape[1], x.shape[1], 3, 3, dtype=torch.float64, device=x.device, requires_grad=True)
+    return torch.autograd.grad(F.conv2d(xd, wd, None, padding=1), wd, go.double())[0]
+
+
+@pytest.mark.parametrize('shape', WRW_SHAPES)
+def test_wino_weight_gradient_matches_fp64(shape):
+    from video_frame_inpainting_amd import conv_ops
+    N, C, K, H, W = shape
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    go = torch.randn(N, K, H, W, generator=g).cuda()
+    got = conv_ops.wino_weight_grad(x, go)
+    assert got is not None and got.shape == (K, C, 3, 3) and torch.isfinite(got).all()
+    ref = _weight_grad_fp64(x, go)
+    # sums of N*H*W products of unit-variance terms: the fp32 error scales with sqrt(count) times the term size
+    scale = (N * H * W) ** 0.5
+    err = (got.double() - ref).abs().max().item() / scale
+    assert err <= 2e-5, err
+    again = conv_ops.wino_weight_grad(x, go)
+    assert torch.equal(got, again)                      # fixed reduction order: reproducible
+
+
+def test_wino_weight_gradient_exact_on_small_integers():
+    """Integer-valued operands keep every Winograd intermediate exact in fp32 (the transforms only add, the 1/2 and 1/4
+    factors of G^T . G are exact), so the result must equal the integer sums bit for bit."""
+    from video_frame_inpainting_amd import conv_ops
+    g = torch.Generator().manual_seed(5)
+    N, C, K, H, W = 3, 24, 40, 16, 32
+    x = torch.randint(-3, 4, (N, C, H, W), generator=g).float().cuda()
+    go = torch.randint(-2, 3, (N, K, H, W), generator=g).float().cuda()
+    got = conv_ops.wino_weight_grad(x, go)
+    ref = _weight_grad_fp64(x, go)
+    assert torch.equal(got.double(), ref)
+
+
+def test_wino_weight_gradient_sees_the_zero_padding_and_every_tap():
+    """One non-zero output-gradient pixel in a corner and one in the interior: dw[k, c, a, b] = x[c, y + a - 1, x + b - 1]
+    with zeros outside the image."""
+    from video_frame_inpainting_amd import conv_ops
+    N, C, K, H, W = 1, 8, 8, 8, 16
+    x = torch.arange(N * C * H * W, dtype=torch.float32).view(N, C, H, W).cuda() % 17 - 8
+    for (py, px) in ((0, 0), (H - 1, W - 1), (3, 7), (0, 9), (5, 0)):
+        go = torch.zeros(N, K, H, W, device='cuda')
+        go[0, 2, py, px] = 1.0
+        got = conv_ops.wino_weight_grad(x, go)
+        xp = F.pad(x, (1, 1, 1, 1))
+        want = torch.zeros(K, C, 3, 3, device='cuda')
+        want[2] = xp[0, :, py:py + 3, px:px + 3]
+        assert torch.equal(got, want), (py, px)
+
+
+def test_wino_weight_gradient_declines_unsupported_shapes():
+    from video_frame_inpainting_amd import _native, conv_ops
+    x = torch.randn(1, 8, 6, 24, device='cuda')                   # W not a multiple of 16
+    assert conv_ops.wino_weight_grad(x, torch.randn(1, 8, 6, 24, device='cuda')) is None
+    x = torch.randn(1, 8, 5, 16, device='cuda')                   # odd H
+    assert conv_ops.wino_weight_grad(x, torch.randn(1, 8, 5, 16, device='cuda')) is None
+    L = _native.lib()
+    assert L.tai_conv3x3_wino_wrw_workspace_floats(64, 512, 64, 128, 128) == -1       # 2 GiB input
+    assert L.tai_conv3x3_wino_wrw(None, None, None, None, 1, 8, 8, 4, 16, None) != 0

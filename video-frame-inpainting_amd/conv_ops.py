@@ -257,10 +257,34 @@ def _wino_launch(x, U, bias, N, Ci, Co, H, W, act):
     return y
 
 
+_WRW_WORKSPACE = {}
+
+
+def wino_weight_grad(x, grad_out):
+    """dL/dw [Co, Ci, 3, 3] of y = conv2d(x, w, padding=1) from x [N, Ci, H, W] and dL/dy [N, Co, H, W], by
+    ``tai_conv3x3_wino_wrw`` (Winograd-domain weight gradient on the fp32 MFMA pipe); None if the shape is not supported
+    (odd H, W not a multiple of 16, a tensor of 2 GiB or more).  The workspace (partial sums per workgroup) is kept per
+    device and grows to the largest request."""
+    N, Ci, H, W = x.shape
+    Co = grad_out.shape[1]
+    L = _native.lib()
+    floats = L.tai_conv3x3_wino_wrw_workspace_floats(N, Ci, Co, H, W)
+    if floats < 0:
+        return None
+    ws = _WRW_WORKSPACE.get(x.device)
+    if ws is None or ws.numel() < floats:
+        ws = _WRW_WORKSPACE[x.device] = torch.empty(floats, dtype=torch.float32, device=x.device)
+    dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _native.check(L.tai_conv3x3_wino_wrw(x.data_ptr(), grad_out.data_ptr(), dw.data_ptr(), ws.data_ptr(), N, Ci, Co, H, W,
+                                             torch.cuda.current_stream(x.device).cuda_stream), 'tai_conv3x3_wino_wrw')
+    return dw
+
+
 class _WinoConv3x3(torch.autograd.Function):
     """Training form of the 3x3 convolution: the forward and the input gradient (the same convolution with the weight
-    transposed and flipped) run on the Winograd-MFMA kernel; the weight and bias gradients are MIOpen's
-    (aten.convolution_backward).  ``transposed``: the weight is a ConvTranspose2d(k 3, stride 1, padding 1) weight."""
+    transposed and flipped) run on the Winograd-MFMA kernel, the weight gradient on its Winograd-domain counterpart
+    (wino_weight_grad; MIOpen's aten.convolution_backward for shapes that one does not take).  ``transposed``: the weight is a ConvTranspose2d(k 3, stride 1, padding 1) weight."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act, transposed):
@@ -287,12 +311,15 @@ class _WinoConv3x3(torch.autograd.Function):
             # d/dx of conv(x, w_eff) is conv(g, w_eff transposed and flipped): the other orientation of the same weight
             zero = torch.zeros(Ci, dtype=g.dtype, device=g.device)
             gx = _wino_launch(g, _wino_weights(weight, not ctx.transposed), zero, N, Co, Ci, H, W, None)
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            w_eff = _as_conv_weight(weight, ctx.transposed)
-            _, gw_eff, gb = torch.ops.aten.convolution_backward(g, x, w_eff, [Co], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                                [False, ctx.needs_input_grad[1], ctx.needs_input_grad[2]])
-            if ctx.needs_input_grad[1]:
-                gw = _as_conv_weight(gw_eff, ctx.transposed)      # the transpose-and-flip is its own inverse
+        if ctx.needs_input_grad[1]:
+            gw_eff = wino_weight_grad(x, g) if g.dtype == torch.float32 and x.dtype == torch.float32 else None
+            if gw_eff is None:                                    # shapes the Winograd weight-gradient kernel does not take
+                w_eff = _as_conv_weight(weight, ctx.transposed)
+                gw_eff = torch.ops.aten.convolution_backward(g, x, w_eff, [Co], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                             [False, True, False])[1]
+            gw = _as_conv_weight(gw_eff, ctx.transposed)          # the transpose-and-flip is its own inverse
+        if ctx.needs_input_grad[2]:
+            gb = g.sum((0, 2, 3))
         return gx, gw, gb, None, None
 
 

@@ -19,6 +19,7 @@
 #include "bias_act.hip.inc"
 #include "thin_conv.hip.inc"
 #include "wino_conv.hip.inc"
+#include "wino_wrw.hip.inc"
 #include "spectral_norm.hip.inc"
 
 namespace {
@@ -453,6 +454,68 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
                        C, Kpad, Cpad);
     return check_launch("wino_transform_weights");
 }
+
+// Split of the weight-gradient kernel's reduction (the tiles) over workgroups: about one workgroup per CU in total.
+struct WrwPlan { int kblocks, cblocks, nchunks, chunks_per_split, splits; };
+static bool wrw_plan(int N, int C, int K, int H, int W, WrwPlan& p) {
+    if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || H % 2 != 0 || W % 16 != 0) return false;
+    if ((long long)N * C * H * W * 4 >= (1LL << 31) || (long long)N * K * H * W * 4 >= (1LL << 31)) return false;
+    p.kblocks = (K + 63) / 64;
+    p.cblocks = (C + 63) / 64;
+    p.nchunks = (int)((long long)N * (H / 2) * (W / 2) / wino::wrw::CT);
+    int want = 256 / (p.kblocks * p.cblocks);
+    if (want < 1) want = 1;
+    if (want > p.nchunks) want = p.nchunks;
+    p.chunks_per_split = (p.nchunks + want - 1) / want;
+    p.splits = (p.nchunks + p.chunks_per_split - 1) / p.chunks_per_split;
+    return true;
+}
+
+long long tai_conv3x3_wino_wrw_workspace_floats(int N, int C, int K, int H, int W) {
+    WrwPlan p;
+    if (!wrw_plan(N, C, K, H, W, p)) return -1;
+    return (long long)p.splits * 9 * p.kblocks * 64 * p.cblocks * 64;
+}
+
+static int wino_wrw_impl(const float* x, const float* dy, float* dw, float* workspace, int N, int C, int K, int H, int W,
+                         void* hip_stream, long long* stamps) {
+    g_err[0] = 0;
+    if (!x || !dy || !dw || !workspace) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    WrwPlan p;
+    if (!wrw_plan(N, C, K, H, W, p))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_wrw: needs even H, W % 16 == 0 and tensors below 2 GiB");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const int grid = p.kblocks * p.cblocks * p.splits;
+    if (stamps) {
+        auto kern = wino::wrw::conv3x3_wrw<2>;
+        if (int rc = allow_lds(kern, wino::wrw::LDS_BYTES)) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), wino::wrw::LDS_BYTES, stream, x, dy, workspace, N, C, K, H, W, p.kblocks,
+                           p.cblocks, p.chunks_per_split, p.nchunks, stamps);
+    } else {
+        auto kern = wino::wrw::conv3x3_wrw<0>;
+        if (int rc = allow_lds(kern, wino::wrw::LDS_BYTES)) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), wino::wrw::LDS_BYTES, stream, x, dy, workspace, N, C, K, H, W, p.kblocks,
+                           p.cblocks, p.chunks_per_split, p.nchunks, stamps);
+    }
+    if (int rc = check_launch("conv3x3_wino_wrw")) return rc;
+    const long long total = 9LL * K * C;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wino::wrw::wrw_reduce, dim3(blocks), dim3(256), 0, stream, workspace, dw, K, C, p.kblocks * 64,
+                       p.cblocks * 64, p.splits);
+    return check_launch("conv3x3_wino_wrw_reduce");
+}
+
+int tai_conv3x3_wino_wrw(const float* x, const float* dy, float* dw, float* workspace, int N, int C, int K, int H, int W,
+                         void* hip_stream) {
+    return wino_wrw_impl(x, dy, dw, workspace, N, C, K, H, W, hip_stream, nullptr);
+}
+
+#ifdef TAI_TIMING_VARIANTS
+int tai_conv3x3_wino_wrw_timeline(const float* x, const float* dy, float* dw, float* workspace, int N, int C, int K, int H,
+                                  int W, long long* stamps, void* hip_stream) {
+    return wino_wrw_impl(x, dy, dw, workspace, N, C, K, H, W, hip_stream, stamps);
+}
+#endif
 
 struct WinoExtras {                       // optional arguments of the general entry point (tai_conv3x3_wino_forward_ex)
     int shift_s = 0;                      // > 0: ONE input tensor read shift_s x shift_s times, displaced by (3a, 3b)
