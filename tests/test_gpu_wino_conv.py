@@ -418,3 +418,30 @@ def test_wino_weight_gradient_declines_unsupported_shapes():
     L = _native.lib()
     assert L.tai_conv3x3_wino_wrw_workspace_floats(64, 512, 64, 128, 128) == -1       # 2 GiB input
     assert L.tai_conv3x3_wino_wrw(None, None, None, None, 1, 8, 8, 4, 16, None) != 0
+
+
+@pytest.mark.parametrize('k,shape', [(5, (16, 64, 128, 64, 64)), (7, (16, 128, 256, 32, 32))])
+@pytest.mark.parametrize('act', [None, 'relu'])
+def test_5x5_and_7x7_training_form_gradients_match_autograd_of_conv2d(k, shape, act):
+    """MotionEnc's 5x5 / 7x7 layers under autograd: forward and input gradient through the Winograd kernel over shifted
+    copies (the input gradient with the transposed, flipped filter), weight / bias gradients from MIOpen / a sum."""
+    from video_frame_inpainting_amd import conv_ops
+    N, C, K, H, W = shape
+    g = torch.Generator().manual_seed(k * 10 + H)
+    x = torch.randn(N, C, H, W, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(K, C, k, k, generator=g) * 0.03).cuda().requires_grad_(True)
+    b = torch.randn(K, generator=g).cuda().requires_grad_(True)
+    go = torch.randn(N, K, H, W, generator=g).cuda()
+    y = conv_ops.conv_bias_act(x, w, b, k // 2, act)
+    assert type(y.grad_fn).__name__ == '_WinoConvKxKBackward'
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), go)
+    assert ('wino_kxk', True) in w._tai_derived
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yd = F.conv2d(xd, wd, bd, padding=k // 2)
+    # the ReLU's mask is taken from the fp32 output: a pre-activation within rounding of zero (there are a few among the
+    # 4M outputs of 6,272-term sums) may open in one precision and not in the other, and that is not what is tested here
+    yd = yd * (y.detach() > 0) if act == 'relu' else yd
+    rx, rw, rb = torch.autograd.grad(yd, (xd, wd, bd), go.double())
+    for got, ref, tol in ((y, yd, 1e-5), (gx, rx, 2e-4), (gw, rw, 2e-4), (gb, rb, 2e-4)):
+        err = (got.double() - ref).abs().max().item() / (1 + ref.abs().max().item())
+        assert err <= tol, err

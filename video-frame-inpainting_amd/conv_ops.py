@@ -82,9 +82,11 @@ def _block3x3_weight(weight):
     return wp.reshape(K, S * S * C, 3, 3).contiguous()
 
 
-def _wino_weights_kxk(weight):
+def _wino_weights_kxk(weight, transposed=False):
+    """``transposed``: the filter of the input-gradient convolution, weight[k, c, a, b] -> [c, k, K-1-a, K-1-b]."""
     def make():
-        w = _block3x3_weight(weight.detach())
+        w = weight.detach()
+        w = _block3x3_weight(w.transpose(0, 1).flip(2, 3).contiguous() if transposed else w)
         K, C = w.shape[0], w.shape[1]
         L = _native.lib()
         U = torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), dtype=torch.float32, device=w.device)
@@ -93,20 +95,21 @@ def _wino_weights_kxk(weight):
                                                                torch.cuda.current_stream(w.device).cuda_stream),
                           'tai_conv3x3_wino_transform_weights')
         return U
-    return _cached(weight, ('wino_kxk', False), make)
+    return _cached(weight, ('wino_kxk', transposed), make)
 
 
-def _kxk_as_wino(x, weight, bias, act, pool):
+def _kxk_as_wino(x, weight, bias, act, pool, transposed=False):
     """5x5 / 7x7 "same" convolution as the Winograd 3x3 kernel over S*S shifted copies of the input (csrc/thin_conv.hip.inc,
-    shift_stack): 1.56x / 1.36x fewer multiplies than the direct form MIOpen runs.  Returns y or (y, pooled)."""
+    shift_stack): 1.56x / 1.36x fewer multiplies than the direct form MIOpen runs.  Returns y or (y, pooled).
+    ``transposed``: convolve with the transposed and flipped filter (the input gradient of the same layer)."""
     N, C, H, W = x.shape
-    K, k = weight.shape[0], weight.shape[2]
+    K, k = weight.shape[1 if transposed else 0], weight.shape[2]
     S = (k + 2) // 3
     L = _native.lib()
     stream = torch.cuda.current_stream(x.device).cuda_stream
     x = x.contiguous()
     stack = torch.empty((N, S * S * C, H + 2, W + 4), dtype=x.dtype, device=x.device)     # shifted copies, own halo
-    U = _wino_weights_kxk(weight)
+    U = _wino_weights_kxk(weight, transposed)
     y = torch.empty((N, K, H, W), dtype=x.dtype, device=x.device)
     yp = torch.empty((N, K, H // 2, W // 2), dtype=x.dtype, device=x.device) if pool else None
     with torch.cuda.device(x.device):
@@ -301,7 +304,7 @@ class _WinoConv3x3(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         g = grad_out.contiguous()
         if ctx.act == 'relu':
-            g = g * (y > 0).to(g.dtype)
+            g = torch.ops.aten.threshold_backward(g, y, 0)        # g where y > 0, else 0: one kernel
         elif ctx.act == 'tanh':
             g = g * (1 - y * y)
         N, Ci, H, W = x.shape
@@ -321,6 +324,38 @@ class _WinoConv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             gb = g.sum((0, 2, 3))
         return gx, gw, gb, None, None
+
+
+class _WinoConvKxK(torch.autograd.Function):
+    """Training form of the 5x5 / 7x7 convolutions (MotionEnc, mcnet.py:36-47): forward and input gradient as 3x3 blocks on
+    the Winograd-MFMA kernel (_kxk_as_wino), weight gradient from MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x = x.contiguous()
+        y = _kxk_as_wino(x, weight, bias, act, False)
+        ctx.act = act
+        ctx.save_for_backward(x, weight, y if act is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, y = ctx.saved_tensors
+        g = grad_out.contiguous()
+        if ctx.act == 'relu':
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        elif ctx.act == 'tanh':
+            g = g * (1 - y * y)
+        Co, Ci, k = weight.shape[0], weight.shape[1], weight.shape[2]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _kxk_as_wino(g, weight, torch.zeros(Ci, dtype=g.dtype, device=g.device), None, False, transposed=True)
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(g, x, weight, [Co], [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        if ctx.needs_input_grad[2]:
+            gb = g.sum((0, 2, 3))
+        return gx, gw, gb, None
 
 
 def conv_bias_act_maxpool(x, weight, bias, padding, act):
@@ -401,6 +436,12 @@ def _conv_bias_act(x, weight, bias, padding, act, transposed, out):
             N, _, H, W = x.shape
             if _wino_ok(N, Ci, Co, H, W, 3, 3, padding) and _wino_ok(N, Co, Ci, H, W, 3, 3, padding):
                 return _WinoConv3x3.apply(x, weight, bias, act, transposed)      # training: autograd through the HIP kernel
+        if (x.is_cuda and x.dtype == torch.float32 and bias is not None and not transposed and weight.shape[2] == weight.shape[3]
+                and weight.shape[2] in (5, 7)):
+            Co, Ci, k = weight.shape[0], weight.shape[1], weight.shape[2]
+            N, _, H, W = x.shape
+            if _kxk_ok(N, Ci, Co, H, W, k, k, padding) and _kxk_ok(N, Co, Ci, H, W, k, k, padding):
+                return _WinoConvKxK.apply(x, weight, bias, act)
         y = F.conv2d(x, _as_conv_weight(weight, transposed), bias, stride=1, padding=padding)
         return torch.relu(y) if act == 'relu' else (torch.tanh(y) if act == 'tanh' else y)
     kh, kw = weight.shape[2], weight.shape[3]

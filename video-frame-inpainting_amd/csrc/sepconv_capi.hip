@@ -498,8 +498,8 @@ static int wino_wrw_impl(const float* x, const float* dy, float* dw, float* work
                            p.cblocks, p.chunks_per_split, p.nchunks, stamps);
     }
     if (int rc = check_launch("conv3x3_wino_wrw")) return rc;
-    const long long total = 9LL * K * C;
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    const long long rows = 9LL * K * p.cblocks;
+    const int blocks = (int)(rows < 8192 ? rows : 8192);
     hipLaunchKernelGGL(wino::wrw::wrw_reduce, dim3(blocks), dim3(256), 0, stream, workspace, dw, K, C, p.kblocks * 64,
                        p.cblocks * 64, p.splits);
     return check_launch("conv3x3_wino_wrw_reduce");
