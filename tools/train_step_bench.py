@@ -13,14 +13,17 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dev = torch.device('cuda:0')
 torch.manual_seed(0); np.random.seed(0)
 model = vfi.create_model('TAI_gray')
-env = create_training_environment(model, 1, '/tmp/ckpt_bench', 'x', 5, 5, 5, [128, 128], 1.0, 0.02, 1e-4, 0.5, 64, 3, 3, [0, 0], device=dev)
+env = create_training_environment(model, 1, '/tmp/ckpt_bench', 'x', 5, 5, 5, [128, 128], 1.0, 0.02, 1e-4, 0.5, 64, 3, 3, [0, 0], device=dev,
+                                  graph_step=os.environ.get('TAI_GRAPH_STEP') == '1')
 env.sync_replicas()
 clips = torch.from_numpy(synthetic.make_clips(B, 15, 1, 128, 128, 1003))
 def step():
-    env.set_train_inputs(clips[:, :5], clips[:, 10:], clips[:, 5:10])
     env.K, env.T, env.F = 5, 5, 5
-    env.train(); env.forward_train(); env.optimize_parameters()
+    env.train(); env.train_step(clips[:, :5], clips[:, 10:], clips[:, 5:10])
 t0 = time.time(); step(); torch.cuda.synchronize(); print('[train] first step %.1f s' % (time.time() - t0), flush=True)
+for _ in range(3):      # with TAI_GRAPH_STEP=1: the second eager warm-up, the capture, a first replay
+    step()
+torch.cuda.synchronize()
 t0 = time.time()
 for i in range(steps):
     step()

@@ -52,7 +52,8 @@ def main(args=None):
     model = vfi.create_model(opt.model_key)
     env = create_training_environment(model, opt.c_dim, opt.checkpoints_dir, opt.name, opt.K, opt.T, opt.F,
                                       opt.image_size, opt.alpha, opt.beta, opt.lr, opt.beta1, opt.df_dim, opt.Ip,
-                                      opt.disc_window_size, opt.padding_size, device=device)
+                                      opt.disc_window_size, opt.padding_size, device=device,
+                                      graph_step=opt.graph_step)
     env.sync_replicas()
     total_updates = env.start_update
     order = np.random.RandomState(opt.seed + 7 * rank)
@@ -62,11 +63,10 @@ def main(args=None):
         env.total_updates = total_updates
         K, T, F = env.sample_KTF(opt.sample_KTF)
         all_frames = next(stream) if loader is not None else clips[order.randint(0, n_clips, opt.batch_size)]
-        env.set_train_inputs(all_frames[:, :K], all_frames[:, K + T:K + T + F], all_frames[:, K:K + T])
         env.K, env.T, env.F = K, T, F
         env.train()
-        env.forward_train()
-        env.optimize_parameters()
+        # set_train_inputs -> forward_train -> optimize_parameters; one hipGraph replay per update with --graph_step
+        env.train_step(all_frames[:, :K], all_frames[:, K + T:K + T + F], all_frames[:, K:K + T])
         if total_updates % opt.print_freq == 0 or total_updates == 1:
             torch.cuda.synchronize()
             errs = env.get_current_errors()

@@ -42,15 +42,17 @@ def create_eval_environment(fill_in_model, checkpoints_dir, name, snapshot_file_
 
 
 def create_training_environment(fill_in_model, c_dim, checkpoints_dir, name, max_K, max_T, max_F, image_size, alpha,
-                                beta, lr, beta1, df_dim, Ip, disc_window_size, padding_size, device=None):
+                                beta, lr, beta1, df_dim, Ip, disc_window_size, padding_size, device=None, graph_step=False):
     if isinstance(fill_in_model, (TAIFillInModel, TimeWeightedInterpolationFillInModel,
                                   BidirectionalSimpleAverageFillInModel, BidirectionalTimeWeightedAverageFillInModel)):
         env = TAITrainingEnvironment(      # environments.py:29-31
             fill_in_model, checkpoints_dir, name, image_size, c_dim, alpha, beta, lr, beta1,
-                                     df_dim, Ip, disc_window_size, max_K, max_T, max_F, padding_size, device=device)
+                                     df_dim, Ip, disc_window_size, max_K, max_T, max_F, padding_size, device=device,
+                                     graph_step=graph_step)
     elif isinstance(fill_in_model, MCNetFillInModel):
         env = MCNetTrainingEnvironment(fill_in_model, checkpoints_dir, name, image_size, c_dim, alpha, beta, lr, beta1,
-                                       df_dim, Ip, disc_window_size, max_K, max_T, max_F, padding_size, device=device)
+                                       df_dim, Ip, disc_window_size, max_K, max_T, max_F, padding_size, device=device,
+                                       graph_step=graph_step)
     else:
         raise RuntimeError('Tried to create a training environment for object of unsupported type %s'
                            % type(fill_in_model).__name__)
@@ -115,14 +117,22 @@ class BaseVideoFillInEnvironment(object):
 class BaseTrainingEnvironment(BaseVideoFillInEnvironment):
     """environments.py:122-259."""
 
-    def __init__(self, fill_in_model, checkpoints_dir, name, lr, beta1, max_K, max_T, max_F, padding_size, device=None):
+    STEP_GRAPH_WARMUP = 2      # eager updates per (K, T, F, batch shape) before the update is captured
+
+    def __init__(self, fill_in_model, checkpoints_dir, name, lr, beta1, max_K, max_T, max_F, padding_size, device=None,
+                 graph_step=False):
         super().__init__(fill_in_model, checkpoints_dir, name, padding_size, device=device)
+        # graph_step: ``train_step`` captures one whole update (forward, both backward passes, both Adam steps: ~10,000
+        # kernel launches) as a hipGraph after STEP_GRAPH_WARMUP eager updates and replays it; Adam then keeps its step
+        # counter on the device (``capturable``).  Off by default: the eager sequence is the reference's.
+        self.graph_step = bool(graph_step)
+        self._step_graphs = {}
         self.start_update = 0
         self.total_updates = 0
         self.start_sum_avg_psnr_err = 0
         self.start_sum_avg_ssim_err = 0
         self.max_K, self.max_T, self.max_F = max_K, max_T, max_F
-        self.optimizer_G = torch.optim.Adam(self.generator.parameters(), lr=lr, betas=(beta1, 0.999))
+        self.optimizer_G = torch.optim.Adam(self.generator.parameters(), lr=lr, betas=(beta1, 0.999), capturable=self.graph_step)
         self._reducer_G = parallel.GradAllReducer(self.generator.parameters())
         # The reference draws (K, T, F) from the global numpy RNG (environments.py:417-427).  Data-parallel replicas must
         # draw the SAME values every step, and anything else that touches the global RNG on one rank only (a data-loader
@@ -150,6 +160,69 @@ class BaseTrainingEnvironment(BaseVideoFillInEnvironment):
     def forward_train(self):
         self.gen_output = self.generator(self.T, self.preceding_frames, self.following_frames)
 
+    # attributes an update produces (tensors of the captured graph's pool when the update is replayed)
+    _STEP_OUTPUTS = ('gen_output', 'loss_G', 'Lp', 'gdl', 'L_GAN', 'loss_d_fake', 'loss_d_real', 'loss_D', 'Lp_forward',
+                     'Lp_backward', 'gdl_forward', 'gdl_backward')
+
+    def train_step(self, preceding_frames, following_frames, gt_middle_frames):
+        """One update on a batch: set_train_inputs + forward_train + optimize_parameters (src/train.py:147-169), with
+        ``self.K, self.T, self.F`` set by the caller.  With ``graph_step`` (one process; data-parallel runs stay eager) the
+        update is captured once per (K, T, F, batch shape) and replayed from static input buffers."""
+        if not self.graph_step or parallel.world_size() > 1:
+            self.set_train_inputs(preceding_frames, following_frames, gt_middle_frames)
+            self.forward_train()
+            self.optimize_parameters()
+            return
+        key = (self.K, self.T, self.F, tuple(preceding_frames.shape), tuple(following_frames.shape), tuple(gt_middle_frames.shape))
+        state = self._step_graphs.setdefault(key, {'eager': 0})
+        if state['eager'] < self.STEP_GRAPH_WARMUP:       # MIOpen's algorithm search, lazy allocations, Adam's state
+            state['eager'] += 1
+            self.set_train_inputs(preceding_frames, following_frames, gt_middle_frames)
+            self.forward_train()
+            self.optimize_parameters()
+            return
+        if 'graph' not in state:
+            self.set_train_inputs(preceding_frames, following_frames, gt_middle_frames)
+            state['inputs'] = (self.preceding_frames.clone(), self.following_frames.clone(), self.gt_middle_frames.clone())
+            self.preceding_frames, self.following_frames, self.gt_middle_frames = state['inputs']
+            self._prepare_capture()
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            # No tensor that carries autograd history may be released inside the capture or outlive it: the previous
+            # (eager) update's outputs are detached before, this update's before the capture ends.  Either one left alone
+            # ends in a fault inside the HIP runtime when the capture is closed (tools/graph_op_bisect.py gen_keep_out*,
+            # tools/graph_step_bisect.py m0).
+            self._detach_step_outputs()
+            with torch.cuda.graph(graph):
+                self.forward_train()
+                self.optimize_parameters()
+                self._detach_step_outputs()
+            state['graph'] = graph
+            state['outputs'] = {k: getattr(self, k) for k in self._STEP_OUTPUTS if hasattr(self, k)}
+        else:
+            p, f, g = state['inputs']
+            p.copy_(preceding_frames, non_blocking=True)
+            f.copy_(following_frames, non_blocking=True)
+            g.copy_(gt_middle_frames, non_blocking=True)
+            self.preceding_frames, self.following_frames, self.gt_middle_frames = p, f, g
+            for k, v in state['outputs'].items():
+                setattr(self, k, v)
+        state['graph'].replay()
+        # the replay recomputed the derived weights (Winograd-domain filters) BEFORE its optimizer steps and moved no
+        # version counter: whatever runs eagerly next (validation, a snapshot's forward) must rebuild them
+        conv_ops.invalidate_derived()
+
+    def _detach_step_outputs(self):
+        for k in self._STEP_OUTPUTS:
+            v = getattr(self, k, None)
+            if isinstance(v, dict):
+                setattr(self, k, {name: t.detach() for name, t in v.items()})
+            elif torch.is_tensor(v):
+                setattr(self, k, v.detach())
+
+    def _prepare_capture(self):
+        """Host-side work a captured update may not do (host-to-device copies): done here, once."""
+
     def get_current_state_dict(self, total_updates, sum_avg_psnr_err, sum_avg_ssim_err):
         return {
             'updates': total_updates,
@@ -165,6 +238,7 @@ class BaseTrainingEnvironment(BaseVideoFillInEnvironment):
         self.start_sum_avg_psnr_err = snapshot['sum_avg_psnr_err']
         self.start_sum_avg_ssim_err = snapshot['sum_avg_ssim_err']
         self.optimizer_G.load_state_dict(snapshot['optimizer_G'])
+        self._step_graphs.clear()
         return snapshot
 
     def save(self, snapshot_file_name, total_updates, sum_avg_psnr_err, sum_avg_ssim_err):
@@ -204,8 +278,10 @@ class L2GDLDiscTrainingEnvironment(BaseTrainingEnvironment):
     loss_D = BCE(D(fake.detach()), window labels) + BCE(D(real), 1)."""
 
     def __init__(self, fill_in_model, checkpoints_dir, name, image_size, c_dim, alpha, beta, lr, beta1, df_dim, Ip,
-                 disc_t, max_K, max_T, max_F, padding_size, device=None):
-        super().__init__(fill_in_model, checkpoints_dir, name, lr, beta1, max_K, max_T, max_F, padding_size, device=device)
+                 disc_t, max_K, max_T, max_F, padding_size, device=None, graph_step=False):
+        super().__init__(fill_in_model, checkpoints_dir, name, lr, beta1, max_K, max_T, max_F, padding_size, device=device,
+                         graph_step=graph_step)
+        self._fake_labels = {}
         self.loss_Lp = torch.nn.MSELoss()
         self.loss_gdl = GDL()
         self.loss_d = torch.nn.BCEWithLogitsLoss()
@@ -215,7 +291,7 @@ class L2GDLDiscTrainingEnvironment(BaseTrainingEnvironment):
         discriminator = move_to_devices(discriminator, self.device)
         discriminator.apply(weights_init)
         self.discriminator = discriminator
-        self.optimizer_D = torch.optim.Adam(self.discriminator.parameters(), lr=lr, betas=(beta1, 0.999))
+        self.optimizer_D = torch.optim.Adam(self.discriminator.parameters(), lr=lr, betas=(beta1, 0.999), capturable=self.graph_step)
         self._reducer_D = parallel.GradAllReducer(self.discriminator.parameters())
 
     def sync_replicas(self):
@@ -248,10 +324,19 @@ class L2GDLDiscTrainingEnvironment(BaseTrainingEnvironment):
             labels[n - ones_f:] = 1
         return labels
 
+    def _device_fake_labels(self):
+        key = (self.K, self.T, self.F)
+        if key not in self._fake_labels:
+            self._fake_labels[key] = self.create_fake_labels().to(self.device)
+        return self._fake_labels[key]
+
+    def _prepare_capture(self):
+        self._device_fake_labels()
+
     def compute_loss_D(self):
         fake = torch.cat([self.preceding_frames, self.gen_output['pred'], self.following_frames], dim=1).detach()
         h = self.discriminator(fake)
-        labels = self.create_fake_labels().to(self.device).view(1, -1).expand(fake.size(0), -1)
+        labels = self._device_fake_labels().view(1, -1).expand(fake.size(0), -1)
         self.loss_d_fake = self.loss_d(h, labels)
         real = torch.cat([self.preceding_frames, self.gt_middle_frames, self.following_frames], dim=1).detach()
         h_ = self.discriminator(real)

@@ -78,6 +78,8 @@ class TrainOptions(BaseOptions):
         g.add_argument('--no_flip', action='store_true')
         g.add_argument('--sample_KTF', action='store_true',
                        help='Sample the number of preceding, middle, and following frames in each minibatch')
+        g.add_argument('--graph_step', action='store_true',
+                       help='Capture one whole update as a hipGraph per (K, T, F) and replay it (one process per node only)')
         g = self.parser.add_argument_group('Training visualization parameters')
         g.add_argument('--tensorboard_dir', type=str, default='tb')
 
