@@ -108,20 +108,25 @@ int tai_conv_shift_stack(const float* x, float* out, int N, int C, int H, int W,
 /* Weight gradient of the 3x3 stride-1 padding-1 convolution y = conv(x, w) (the reference's nn.Conv2d / ConvTranspose2d
  * 3x3 layers under loss.backward(), src/environments/environments.py:348-355), in the Winograd domain on the fp32 MFMA pipe:
  *   dw [K, C, 3, 3] = sum over n, y, x of dy[n, k, y, x] * x[n, c, y + a - 1, x + b - 1]      (zero padding)
+ * and, when dbias is not NULL, the bias gradient dbias [K] = sum over n, y, x of dy[n, k, y, x] (the output gradient
+ * passes through the kernel anyway).
  * x [N, C, H, W], dy [N, K, H, W] fp32 contiguous, H even, W % 16 == 0, each tensor below 2 GiB.  workspace: device memory
  * of tai_conv3x3_wino_wrw_workspace_floats(...) floats (-1: shape not supported), overwritten.  Partial sums of the
- * workgroups are combined in a fixed order: the result is reproducible from call to call. */
+ * workgroups are combined in a fixed order: the results are reproducible from call to call. */
 long long tai_conv3x3_wino_wrw_workspace_floats(int N, int C, int K, int H, int W);
-int tai_conv3x3_wino_wrw(const float* x, const float* dy, float* dw, float* workspace, int N, int C, int K, int H, int W,
-                         void* hip_stream);
+int tai_conv3x3_wino_wrw(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int N, int C, int K, int H,
+                         int W, void* hip_stream);
 
 /* Spectral normalisation of one discriminator layer, as the reference's SNConv2d / SNLinear do on every forward
  * (src/discriminators/SNDiscriminator.py:10-25 max_singular_value, :60-68 and :84-92 W.data <- W.data / sigma):
  * Ip rounds of  v <- normalise(u W), u <- normalise(v W^T)  on weight [out_rows, in_cols] (the layer's weight viewed as a
  * matrix, fp32 contiguous), sigma = (v W^T) u^T, then weight /= sigma IN PLACE and u [out_rows] replaced by the new
- * vector.  scratch: at least in_cols + out_rows + 1 floats of device memory; the last one receives sigma.  2 Ip + 1
- * kernel launches on hip_stream, nothing synchronises. */
-int tai_sn_power_iteration(float* weight, float* u, float* scratch, int out_rows, int in_cols, int Ip, void* hip_stream);
+ * vector.  scratch: at least in_cols + out_rows floats of device memory.  sigma_out: one float of device memory that
+ * receives sigma (may be NULL) -- a caller that renormalises the same layer several times in a row (the discriminator's
+ * sliding windows) passes consecutive slots of one vector and gets the cumulative scale of every window from it.
+ * 2 Ip + 1 kernel launches on hip_stream, nothing synchronises. */
+int tai_sn_power_iteration(float* weight, float* u, float* scratch, float* sigma_out, int out_rows, int in_cols, int Ip,
+                           void* hip_stream);
 
 /* 3x3 stride-1 zero-padded ("same") convolution + bias + activation, fp32 NCHW contiguous, H and W even, computed as
  * Winograd F(2x2,3x3) on the fp32 MFMA pipe.  Replaces nn.Conv2d(C, K, 3, padding=1) [+ ReLU] of the generator and the

@@ -376,8 +376,12 @@ def test_wino_weight_gradient_matches_fp64(shape):
     scale = (N * H * W) ** 0.5
     err = (got.double() - ref).abs().max().item() / scale
     assert err <= 2e-5, err
-    again = conv_ops.wino_weight_grad(x, go)
+    again, gb = conv_ops.wino_weight_grad(x, go, with_bias=True)
     assert torch.equal(got, again)                      # fixed reduction order: reproducible
+    # the bias gradient summed by the same kernel
+    rb = go.double().sum((0, 2, 3))
+    assert gb.shape == (K,) and float((gb.double() - rb).abs().max()) / scale <= 2e-5
+    assert torch.equal(gb, conv_ops.wino_weight_grad(x, go, with_bias=True)[1])
 
 
 def test_wino_weight_gradient_exact_on_small_integers():
@@ -417,7 +421,7 @@ def test_wino_weight_gradient_declines_unsupported_shapes():
     assert conv_ops.wino_weight_grad(x, torch.randn(1, 8, 5, 16, device='cuda')) is None
     L = _native.lib()
     assert L.tai_conv3x3_wino_wrw_workspace_floats(64, 512, 64, 128, 128) == -1       # 2 GiB input
-    assert L.tai_conv3x3_wino_wrw(None, None, None, None, 1, 8, 8, 4, 16, None) != 0
+    assert L.tai_conv3x3_wino_wrw(None, None, None, None, None, 1, 8, 8, 4, 16, None) != 0
 
 
 @pytest.mark.parametrize('k,shape', [(5, (16, 64, 128, 64, 64)), (7, (16, 128, 256, 32, 32))])

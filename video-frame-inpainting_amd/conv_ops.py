@@ -263,11 +263,12 @@ def _wino_launch(x, U, bias, N, Ci, Co, H, W, act):
 _WRW_WORKSPACE = {}
 
 
-def wino_weight_grad(x, grad_out):
+def wino_weight_grad(x, grad_out, with_bias=False):
     """dL/dw [Co, Ci, 3, 3] of y = conv2d(x, w, padding=1) from x [N, Ci, H, W] and dL/dy [N, Co, H, W], by
     ``tai_conv3x3_wino_wrw`` (Winograd-domain weight gradient on the fp32 MFMA pipe); None if the shape is not supported
-    (odd H, W not a multiple of 16, a tensor of 2 GiB or more).  The workspace (partial sums per workgroup) is kept per
-    device and grows to the largest request."""
+    (odd H, W not a multiple of 16, a tensor of 2 GiB or more).  ``with_bias``: returns (dw, dbias), the bias gradient
+    summed by the same kernel.  The workspace (partial sums per workgroup) is kept per device and grows to the largest
+    request."""
     N, Ci, H, W = x.shape
     Co = grad_out.shape[1]
     L = _native.lib()
@@ -278,10 +279,12 @@ def wino_weight_grad(x, grad_out):
     if ws is None or ws.numel() < floats:
         ws = _WRW_WORKSPACE[x.device] = torch.empty(floats, dtype=torch.float32, device=x.device)
     dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty(Co, dtype=torch.float32, device=x.device) if with_bias else None
     with torch.cuda.device(x.device):
-        _native.check(L.tai_conv3x3_wino_wrw(x.data_ptr(), grad_out.data_ptr(), dw.data_ptr(), ws.data_ptr(), N, Ci, Co, H, W,
-                                             torch.cuda.current_stream(x.device).cuda_stream), 'tai_conv3x3_wino_wrw')
-    return dw
+        _native.check(L.tai_conv3x3_wino_wrw(x.data_ptr(), grad_out.data_ptr(), dw.data_ptr(), db.data_ptr() if with_bias else None,
+                                             ws.data_ptr(), N, Ci, Co, H, W, torch.cuda.current_stream(x.device).cuda_stream),
+                      'tai_conv3x3_wino_wrw')
+    return (dw, db) if with_bias else dw
 
 
 class _WinoConv3x3(torch.autograd.Function):
@@ -315,13 +318,20 @@ class _WinoConv3x3(torch.autograd.Function):
             zero = torch.zeros(Ci, dtype=g.dtype, device=g.device)
             gx = _wino_launch(g, _wino_weights(weight, not ctx.transposed), zero, N, Co, Ci, H, W, None)
         if ctx.needs_input_grad[1]:
-            gw_eff = wino_weight_grad(x, g) if g.dtype == torch.float32 and x.dtype == torch.float32 else None
+            gw_eff = None
+            if g.dtype == torch.float32 and x.dtype == torch.float32:
+                if ctx.needs_input_grad[2]:
+                    both = wino_weight_grad(x, g, with_bias=True)
+                    if both is not None:
+                        gw_eff, gb = both
+                else:
+                    gw_eff = wino_weight_grad(x, g)
             if gw_eff is None:                                    # shapes the Winograd weight-gradient kernel does not take
                 w_eff = _as_conv_weight(weight, ctx.transposed)
                 gw_eff = torch.ops.aten.convolution_backward(g, x, w_eff, [Co], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                              [False, True, False])[1]
             gw = _as_conv_weight(gw_eff, ctx.transposed)          # the transpose-and-flip is its own inverse
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[2] and gb is None:
             gb = g.sum((0, 2, 3))
         return gx, gw, gb, None, None
 

@@ -388,14 +388,15 @@ int tai_convlstm_gates_forward(const float* gates, const float* c, float* new_c,
     return check_launch("convlstm_gates");
 }
 
-int tai_sn_power_iteration(float* weight, float* u, float* scratch, int out_rows, int in_cols, int Ip, void* hip_stream) {
+int tai_sn_power_iteration(float* weight, float* u, float* scratch, float* sigma_out, int out_rows, int in_cols, int Ip,
+                           void* hip_stream) {
     g_err[0] = 0;
     if (!weight || !u || !scratch) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
     if (out_rows <= 0 || in_cols <= 0 || Ip <= 0 || Ip > 64) return fail(TAI_SEPCONV_EINVAL, "%s", "sn_power_iteration: bad shape or Ip");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     float* v_raw = scratch;
     float* t_raw = scratch + in_cols;
-    float* sigma = t_raw + out_rows;
+    float* sigma = sigma_out;
     const dim3 wt_block(snorm::WT_COLS, snorm::WT_ROWGROUPS);
     const int wt_grid = (in_cols + snorm::WT_COLS - 1) / snorm::WT_COLS;
     for (int it = 0; it < Ip; ++it) {
@@ -474,11 +475,11 @@ static bool wrw_plan(int N, int C, int K, int H, int W, WrwPlan& p) {
 long long tai_conv3x3_wino_wrw_workspace_floats(int N, int C, int K, int H, int W) {
     WrwPlan p;
     if (!wrw_plan(N, C, K, H, W, p)) return -1;
-    return (long long)p.splits * 9 * p.kblocks * 64 * p.cblocks * 64;
+    return (long long)p.splits * 9 * p.kblocks * 64 * p.cblocks * 64 + (long long)p.splits * p.kblocks * 64;     // taps, then bias partials
 }
 
-static int wino_wrw_impl(const float* x, const float* dy, float* dw, float* workspace, int N, int C, int K, int H, int W,
-                         void* hip_stream, long long* stamps) {
+static int wino_wrw_impl(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int N, int C, int K, int H,
+                         int W, void* hip_stream, long long* stamps) {
     g_err[0] = 0;
     if (!x || !dy || !dw || !workspace) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
     WrwPlan p;
@@ -486,34 +487,35 @@ static int wino_wrw_impl(const float* x, const float* dy, float* dw, float* work
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_wrw: needs even H, W % 16 == 0 and tensors below 2 GiB");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const int grid = p.kblocks * p.cblocks * p.splits;
+    float* wsb = dbias ? workspace + (long long)p.splits * 9 * p.kblocks * 64 * p.cblocks * 64 : nullptr;
     if (stamps) {
         auto kern = wino::wrw::conv3x3_wrw<2>;
         if (int rc = allow_lds(kern, wino::wrw::LDS_BYTES)) return rc;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), wino::wrw::LDS_BYTES, stream, x, dy, workspace, N, C, K, H, W, p.kblocks,
-                           p.cblocks, p.chunks_per_split, p.nchunks, stamps);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), wino::wrw::LDS_BYTES, stream, x, dy, workspace, wsb, N, C, K, H, W,
+                           p.kblocks, p.cblocks, p.chunks_per_split, p.nchunks, stamps);
     } else {
         auto kern = wino::wrw::conv3x3_wrw<0>;
         if (int rc = allow_lds(kern, wino::wrw::LDS_BYTES)) return rc;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), wino::wrw::LDS_BYTES, stream, x, dy, workspace, N, C, K, H, W, p.kblocks,
-                           p.cblocks, p.chunks_per_split, p.nchunks, stamps);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), wino::wrw::LDS_BYTES, stream, x, dy, workspace, wsb, N, C, K, H, W,
+                           p.kblocks, p.cblocks, p.chunks_per_split, p.nchunks, stamps);
     }
     if (int rc = check_launch("conv3x3_wino_wrw")) return rc;
     const long long rows = 9LL * K * p.cblocks;
     const int blocks = (int)(rows < 8192 ? rows : 8192);
-    hipLaunchKernelGGL(wino::wrw::wrw_reduce, dim3(blocks), dim3(256), 0, stream, workspace, dw, K, C, p.kblocks * 64,
-                       p.cblocks * 64, p.splits);
+    hipLaunchKernelGGL(wino::wrw::wrw_reduce, dim3(blocks), dim3(256), 0, stream, workspace, dw, wsb, dbias, K, C,
+                       p.kblocks * 64, p.cblocks * 64, p.splits);
     return check_launch("conv3x3_wino_wrw_reduce");
 }
 
-int tai_conv3x3_wino_wrw(const float* x, const float* dy, float* dw, float* workspace, int N, int C, int K, int H, int W,
-                         void* hip_stream) {
-    return wino_wrw_impl(x, dy, dw, workspace, N, C, K, H, W, hip_stream, nullptr);
+int tai_conv3x3_wino_wrw(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int N, int C, int K, int H,
+                         int W, void* hip_stream) {
+    return wino_wrw_impl(x, dy, dw, dbias, workspace, N, C, K, H, W, hip_stream, nullptr);
 }
 
 #ifdef TAI_TIMING_VARIANTS
 int tai_conv3x3_wino_wrw_timeline(const float* x, const float* dy, float* dw, float* workspace, int N, int C, int K, int H,
                                   int W, long long* stamps, void* hip_stream) {
-    return wino_wrw_impl(x, dy, dw, workspace, N, C, K, H, W, hip_stream, stamps);
+    return wino_wrw_impl(x, dy, dw, nullptr, workspace, N, C, K, H, W, hip_stream, stamps);
 }
 #endif
 

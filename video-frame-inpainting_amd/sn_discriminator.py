@@ -64,7 +64,8 @@ class _SpectralNormalised(object):
                 weight.data = weight.data / sigma     # in place, cumulative: SNDiscriminator.py:67,91
         return weight + 0 if torch.is_grad_enabled() and weight.requires_grad else weight
 
-    def _renormalise_native_(self):
+    def _renormalise_native_(self, sigma_out=None):
+        """One renormalisation on the GPU; sigma goes to ``sigma_out`` (a one-element device view) or to the layer's own slot."""
         from . import _native
         weight = self.weight
         out_rows = weight.size(0)
@@ -77,15 +78,91 @@ class _SpectralNormalised(object):
         scratch = getattr(self, '_sn_scratch', None)
         if scratch is None or scratch.device != weight.device or scratch.numel() != in_cols + out_rows + 1:
             scratch = self._sn_scratch = torch.empty(in_cols + out_rows + 1, device=weight.device, dtype=torch.float32)
+        sigma = scratch[-1:] if sigma_out is None else sigma_out
         with torch.cuda.device(weight.device):
             _native.check(_native.lib().tai_sn_power_iteration(
-                weight.data_ptr(), u.data_ptr(), scratch.data_ptr(), out_rows, in_cols, int(self.Ip),
+                weight.data_ptr(), u.data_ptr(), scratch.data_ptr(), sigma.data_ptr(), out_rows, in_cols, int(self.Ip),
                 torch.cuda.current_stream(weight.device).cuda_stream), 'tai_sn_power_iteration')
 
     @property
     def last_sigma(self):
-        """sigma of the most recent GPU renormalisation (a device scalar), for tests and diagnostics."""
+        """sigma of the most recent single GPU renormalisation (a device scalar), for tests and diagnostics."""
         return self._sn_scratch[-1:] if getattr(self, '_sn_scratch', None) is not None else None
+
+    def renormalise_sequence_(self, count):
+        """``count`` renormalisations in a row (what ``count`` consecutive forwards do to the parameter; none of them
+        depends on the data).  Returns (w0, inv_scale): the weight before the first one, and inv_scale[t] = 1 / (sigma_1 ...
+        sigma_{t+1}), so that the weight forward t+1 of the reference convolves with is w0 * inv_scale[t]."""
+        w0 = self.weight.detach().clone()
+        sigmas = torch.empty(count, device=self.weight.device, dtype=torch.float32)
+        for t in range(count):
+            self._renormalise_native_(sigmas[t:t + 1])
+        return w0, torch.cumprod(sigmas, 0).reciprocal_()
+
+
+class _WindowScaledConv(torch.autograd.Function):
+    """y[t] = conv(x[t], w0) * inv_scale[t] + bias for the ``nw`` window groups stacked along the batch: the convolution
+    of window t with the weight the reference holds at that moment, w0 * inv_scale[t] (SNDiscriminator.py:60-68), as ONE
+    convolution over all windows.  Gradients as the reference's autograd produces them: every window differentiates with
+    respect to ITS weight tensor and the results accumulate in the parameter (so the weight gradient takes the output
+    gradient unscaled), the input gradient goes through w0 * inv_scale[t]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, w0, bias, inv_scale, nw, stride, padding):
+        y = F.conv2d(x, w0, None, stride, padding)
+        N = y.shape[0]
+        y = (y.view(nw, N // nw, -1) * inv_scale.view(nw, 1, 1)).view_as(y)
+        if bias is not None:
+            y = y + bias.view(1, -1, 1, 1)
+        ctx.save_for_backward(x, w0, inv_scale)
+        ctx.cfg = (nw, stride, padding, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w0, inv_scale = ctx.saved_tensors
+        nw, stride, padding, has_bias = ctx.cfg
+        g = g.contiguous()
+        N, Co = g.shape[0], g.shape[1]
+        gx = gw = gb = None
+        conv_bwd = torch.ops.aten.convolution_backward
+        if ctx.needs_input_grad[1]:
+            gw = conv_bwd(g, x, w0, [Co], list(stride), list(padding), [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        if ctx.needs_input_grad[0]:
+            gs = (g.view(nw, N // nw, -1) * inv_scale.view(nw, 1, 1)).view_as(g)
+            gx = conv_bwd(gs, x, w0, [Co], list(stride), list(padding), [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if has_bias and ctx.needs_input_grad[3]:
+            gb = g.sum((0, 2, 3))
+        return gx, gw, None, gb, None, None, None, None
+
+
+class _WindowScaledLinear(torch.autograd.Function):
+    """The same for the one-logit linear layer: y[t] = feats[t] @ w0^T * inv_scale[t] + bias."""
+
+    @staticmethod
+    def forward(ctx, x, weight, w0, bias, inv_scale, nw):
+        y = torch.mv(x, w0.view(-1))
+        y = (y.view(nw, -1) * inv_scale.view(nw, 1)).reshape(-1, 1)
+        if bias is not None:
+            y = y + bias
+        ctx.save_for_backward(x, w0, inv_scale)
+        ctx.nw = nw
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w0, inv_scale = ctx.saved_tensors
+        nw = ctx.nw
+        g = g.reshape(-1)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.mv(x.t(), g).view_as(w0)
+        if ctx.needs_input_grad[0]:
+            gs = (g.view(nw, -1) * inv_scale.view(nw, 1)).reshape(-1)
+            gx = torch.outer(gs, w0.view(-1))
+        if ctx.needs_input_grad[3]:
+            gb = g.sum().view(1)
+        return gx, gw, None, gb, None, None
 
 
 class SNConv2d(nn.Conv2d, _SpectralNormalised):
@@ -132,9 +209,33 @@ class SNDiscriminator(nn.Module):
     def forward(self, input):
         """input [B, T, C, H, W] -> logits [B, T - window_size + 1]."""
         B, T, C, H, W = input.shape
+        nw = T - self.window_size + 1
+        if input.is_cuda and input.dtype == torch.float32 and self.linear_layer.out_features == 1 and nw >= 1 and \
+                all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in self.parameters()):
+            return self._forward_windows_batched(input, nw)
         outs = []
-        for t0 in range(T - self.window_size + 1):
+        for t0 in range(nw):
             window = input[:, t0:t0 + self.window_size].reshape(B, self.window_size * C, H, W)
             feats = self.conv_layers(window).reshape(B, self.num_sn_linear_in_feats)
             outs.append(self.linear_layer(feats))
         return torch.cat(outs, dim=1)
+
+    def _forward_windows_batched(self, input, nw):
+        """All windows in one pass.  The reference evaluates the windows one after the other and every evaluation divides
+        every layer's weight by its spectral norm again (:60-68, :84-92, :140-159): window t sees the weights renormalised
+        t times.  Those renormalisations do not depend on the data and only rescale the weight, so they are done up front
+        (same kernels, same order, the parameter ends in the same state) and the 13 x 5 small convolutions of a K=T=F=5
+        clip become 5 convolutions over 13 B images with one factor per window (_WindowScaledConv)."""
+        B, T, C, H, W = input.shape
+        ws = self.window_size
+        x = torch.stack([input[:, t0:t0 + ws].reshape(B, ws * C, H, W) for t0 in range(nw)], dim=0).view(nw * B, ws * C, H, W)
+        for layer in self.conv_layers:
+            if isinstance(layer, SNConv2d):
+                w0, inv_scale = layer.renormalise_sequence_(nw)
+                x = _WindowScaledConv.apply(x, layer.weight, w0, layer.bias, inv_scale, nw, layer.stride, layer.padding)
+            else:
+                x = layer(x)
+        w0, inv_scale = self.linear_layer.renormalise_sequence_(nw)
+        logits = _WindowScaledLinear.apply(x.reshape(nw * B, self.num_sn_linear_in_feats), self.linear_layer.weight, w0,
+                                           self.linear_layer.bias, inv_scale, nw)
+        return logits.view(nw, B).t().contiguous()
