@@ -116,6 +116,9 @@ int tai_conv_shift_stack(const float* x, float* out, int N, int C, int H, int W,
 long long tai_conv3x3_wino_wrw_workspace_floats(int N, int C, int K, int H, int W);
 int tai_conv3x3_wino_wrw(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int N, int C, int K, int H,
                          int W, void* hip_stream);
+/* Load scheme of the weight-gradient kernel when W % 32 == 0: 1 (default) = chunk pairs over 16 consecutive tiles, whole
+ * 128-byte lines per load; 0 = 8-tile chunks as for the other widths (same results, for A/B timing).  Returns the previous value. */
+int tai_conv3x3_wino_wrw_set_paired(int on);
 
 /* Spectral normalisation of one discriminator layer, as the reference's SNConv2d / SNLinear do on every forward
  * (src/discriminators/SNDiscriminator.py:10-25 max_singular_value, :60-68 and :84-92 W.data <- W.data / sigma):

@@ -384,6 +384,26 @@ def test_wino_weight_gradient_matches_fp64(shape):
     assert torch.equal(gb, conv_ops.wino_weight_grad(x, go, with_bias=True)[1])
 
 
+def test_wino_weight_gradient_paired_and_plain_chunks_agree():
+    """W % 32 == 0 takes the paired-chunk load scheme (whole 128-byte lines); the 8-tile scheme on the same operands sums the
+    same products in another order."""
+    from video_frame_inpainting_amd import _native, conv_ops
+    L = _native.lib()
+    g = torch.Generator().manual_seed(31)
+    for (N, C, K, H, W) in ((3, 24, 40, 16, 32), (2, 64, 64, 64, 64), (5, 13, 70, 6, 96)):
+        x = torch.randn(N, C, H, W, generator=g).cuda()
+        go = torch.randn(N, K, H, W, generator=g).cuda()
+        paired, pb = conv_ops.wino_weight_grad(x, go, with_bias=True)
+        prev = L.tai_conv3x3_wino_wrw_set_paired(0)
+        try:
+            plain, qb = conv_ops.wino_weight_grad(x, go, with_bias=True)
+        finally:
+            L.tai_conv3x3_wino_wrw_set_paired(prev)
+        scale = (N * H * W) ** 0.5
+        assert float((paired - plain).abs().max()) / scale <= 2e-5
+        assert float((pb - qb).abs().max()) / scale <= 2e-5
+
+
 def test_wino_weight_gradient_exact_on_small_integers():
     """Integer-valued operands keep every Winograd intermediate exact in fp32 (the transforms only add, the 1/2 and 1/4
     factors of G^T . G are exact), so the result must equal the integer sums bit for bit."""

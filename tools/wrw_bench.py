@@ -28,6 +28,11 @@ for N, C, K, H, W in SHAPES:
     a, b = ours(), mi()
     err = (a - b).abs().max().item() / b.abs().max().item()
     t_o, t_m = timeit(ours), timeit(mi)
+    L = conv_ops._native.lib()
+    prev = L.tai_conv3x3_wino_wrw_set_paired(0)
+    t_u = timeit(ours)
+    same = torch.equal(ours(), a) if W % 32 else None
+    L.tai_conv3x3_wino_wrw_set_paired(prev)
     flops = 2.0 * N * H * W * C * K * 9
-    print('N%d C%d K%d %dx%d: wino wrw %7.1f us (%5.1f TF direct-equivalent)   MIOpen %7.1f us   x%.2f   max rel diff %.1e' % (
-        N, C, K, H, W, t_o, flops / t_o * 1e-6, t_m, t_m / t_o, err), flush=True)
+    print('N%d C%d K%d %dx%d: wino wrw %7.1f us (%5.1f TF direct-equivalent; 8-tile chunks %7.1f us)   MIOpen %7.1f us   x%.2f   max rel diff %.1e' % (
+        N, C, K, H, W, t_o, flops / t_o * 1e-6, t_u, t_m, t_m / t_o, err), flush=True)

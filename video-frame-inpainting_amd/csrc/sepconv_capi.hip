@@ -457,7 +457,7 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
 }
 
 // Split of the weight-gradient kernel's reduction (the tiles) over workgroups: about one workgroup per CU in total.
-struct WrwPlan { int kblocks, cblocks, nchunks, chunks_per_split, splits; };
+struct WrwPlan { int kblocks, cblocks, nchunks, chunks_per_split, splits, pair; };
 static bool wrw_plan(int N, int C, int K, int H, int W, WrwPlan& p) {
     if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || H % 2 != 0 || W % 16 != 0) return false;
     if ((long long)N * C * H * W * 4 >= (1LL << 31) || (long long)N * K * H * W * 4 >= (1LL << 31)) return false;
@@ -468,6 +468,8 @@ static bool wrw_plan(int N, int C, int K, int H, int W, WrwPlan& p) {
     if (want < 1) want = 1;
     if (want > p.nchunks) want = p.nchunks;
     p.chunks_per_split = (p.nchunks + want - 1) / want;
+    p.pair = W % 32 == 0;                         // chunk pairs over 16 consecutive tiles: whole 128-byte lines per load
+    if (p.pair && (p.chunks_per_split & 1)) ++p.chunks_per_split;      // (the chunk count is even when W % 32 == 0)
     p.splits = (p.nchunks + p.chunks_per_split - 1) / p.chunks_per_split;
     return true;
 }
@@ -477,6 +479,9 @@ long long tai_conv3x3_wino_wrw_workspace_floats(int N, int C, int K, int H, int 
     if (!wrw_plan(N, C, K, H, W, p)) return -1;
     return (long long)p.splits * 9 * p.kblocks * 64 * p.cblocks * 64 + (long long)p.splits * p.kblocks * 64;     // taps, then bias partials
 }
+
+static std::atomic<int> g_wrw_pair{1};              // 1: paired chunks (whole-line loads) when W % 32 == 0
+int tai_conv3x3_wino_wrw_set_paired(int on) { return g_wrw_pair.exchange(on ? 1 : 0, std::memory_order_relaxed); }
 
 static int wino_wrw_impl(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int N, int C, int K, int H,
                          int W, void* hip_stream, long long* stamps) {
@@ -488,17 +493,17 @@ static int wino_wrw_impl(const float* x, const float* dy, float* dw, float* dbia
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const int grid = p.kblocks * p.cblocks * p.splits;
     float* wsb = dbias ? workspace + (long long)p.splits * 9 * p.kblocks * 64 * p.cblocks * 64 : nullptr;
-    if (stamps) {
-        auto kern = wino::wrw::conv3x3_wrw<2>;
-        if (int rc = allow_lds(kern, wino::wrw::LDS_BYTES)) return rc;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), wino::wrw::LDS_BYTES, stream, x, dy, workspace, wsb, N, C, K, H, W,
-                           p.kblocks, p.cblocks, p.chunks_per_split, p.nchunks, stamps);
-    } else {
-        auto kern = wino::wrw::conv3x3_wrw<0>;
-        if (int rc = allow_lds(kern, wino::wrw::LDS_BYTES)) return rc;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), wino::wrw::LDS_BYTES, stream, x, dy, workspace, wsb, N, C, K, H, W,
-                           p.kblocks, p.cblocks, p.chunks_per_split, p.nchunks, stamps);
-    }
+#define TAI_LAUNCH_WRW(D, P)                                                                                                   \
+    do {                                                                                                                       \
+        auto kern = wino::wrw::conv3x3_wrw<D, P>;                                                                              \
+        if (int rc = allow_lds(kern, wino::wrw::LDS_BYTES)) return rc;                                                         \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), wino::wrw::LDS_BYTES, stream, x, dy, workspace, wsb, N, C, K, H, W,   \
+                           p.kblocks, p.cblocks, p.chunks_per_split, p.nchunks, stamps);                                       \
+    } while (0)
+    const bool pair = p.pair && g_wrw_pair.load(std::memory_order_relaxed);
+    if (stamps) { if (pair) TAI_LAUNCH_WRW(2, true); else TAI_LAUNCH_WRW(2, false); }
+    else { if (pair) TAI_LAUNCH_WRW(0, true); else TAI_LAUNCH_WRW(0, false); }
+#undef TAI_LAUNCH_WRW
     if (int rc = check_launch("conv3x3_wino_wrw")) return rc;
     const long long rows = 9LL * K * p.cblocks;
     const int blocks = (int)(rows < 8192 ? rows : 8192);
