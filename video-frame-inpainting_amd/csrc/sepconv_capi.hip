@@ -506,7 +506,7 @@ static int wino_wrw_impl(const float* x, const float* dy, float* dw, float* dbia
 #undef TAI_LAUNCH_WRW
     if (int rc = check_launch("conv3x3_wino_wrw")) return rc;
     const long long rows = 9LL * K * p.cblocks;
-    const int blocks = (int)(rows < 8192 ? rows : 8192);
+    const int blocks = (int)(rows < 8192 ? (rows < p.kblocks ? p.kblocks : rows) : 8192);      // (at least one workgroup per 64 bias entries)
     hipLaunchKernelGGL(wino::wrw::wrw_reduce, dim3(blocks), dim3(256), 0, stream, workspace, dw, wsb, dbias, K, C,
                        p.kblocks * 64, p.cblocks * 64, p.splits);
     return check_launch("conv3x3_wino_wrw_reduce");
