@@ -76,6 +76,15 @@ pmc['note'] = ('hbm_bytes = 2 x FETCH_SIZE(KB) x 1024 + WRITE_SIZE(KB) x 1024: M
                'half the bytes of a wide coalesced streaming read (16 B/lane global_load and LDS-DMA alike); WRITE_SIZE is exact for 16 B/lane '
                'streaming stores. Counters from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE GRBM_GUI_ACTIVE` (separate runs) of '
                '`python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`, dispatches of grid 131072 only.')
+try:       # what bench.py checks before it prints the value as `roofline.traffic`
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from video_frame_inpainting_amd import _native
+    pmc['library_version'] = int(_native.lib().tai_sepconv_version())
+    pmc['forward_variant'] = int(_native.lib().tai_sepconv_default_forward_variant(1, 128, 51))
+except Exception as e:
+    pmc['library_version_error'] = repr(e)
+pmc['source'] = ('tools/collect_r02_evidence.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE GRBM_GUI_ACTIVE / --kernel-trace --stats, separate '
+                 'runs of `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`; dispatches of the [32,1,128,128] roofline shape (grid 131072)')
 json.dump(pmc, open(os.path.join(res_dir, 'sepconv_fwd_pmc_measured.json'), 'w'), indent=1)
 print(json.dumps(pmc, indent=1)[:600])
 

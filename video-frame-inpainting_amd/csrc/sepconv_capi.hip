@@ -224,7 +224,7 @@ int launch_grad_vh_tiled(const float* gO, const float* in, const float* v, const
 
 extern "C" {
 
-int tai_sepconv_version(void) { return 200; }
+int tai_sepconv_version(void) { return 300; }     // 0.3.0: + tai_conv3x3_wino_wrw*, tai_sn_power_iteration, shift_k
 
 const char* tai_sepconv_last_error(void) { return g_err; }
 
