@@ -105,6 +105,15 @@ int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float*
  * 45-47).  W % 4 == 0. */
 int tai_conv_shift_stack(const float* x, float* out, int N, int C, int H, int W, int k, void* hip_stream);
 
+/* Activation + 2x2 max pool behind a convolution, training form (nn.ReLU + nn.MaxPool2d(2) of ContentEnc / MotionEnc,
+ * src/models/mcnet/mcnet.py:28-60, 79-118): z, y [planes, H, W], ypool [planes, H/2, W/2] fp32 contiguous, H even, W % 4 == 0.
+ *   forward:  y = relu ? max(z, 0) : z;  ypool = max over each 2x2 window of y                     (y may alias z)
+ *   backward: grad_z = (relu ? [y > 0] : 1) * (grad_y + grad_ypool routed to the first maximum of its window in row-major
+ *             order, nn.MaxPool2d's tie rule); grad_y or grad_ypool may be NULL (that path carries no gradient). */
+int tai_act_maxpool2x2_forward(const float* z, float* y, float* ypool, long long planes, int H, int W, int relu, void* hip_stream);
+int tai_act_maxpool2x2_backward(const float* grad_y, const float* grad_ypool, const float* y, float* grad_z, long long planes, int H,
+                                int W, int relu, void* hip_stream);
+
 /* Weight gradient of the 3x3 stride-1 padding-1 convolution y = conv(x, w) (the reference's nn.Conv2d / ConvTranspose2d
  * 3x3 layers under loss.backward(), src/environments/environments.py:348-355), in the Winograd domain on the fp32 MFMA pipe:
  *   dw [K, C, 3, 3] = sum over n, y, x of dy[n, k, y, x] * x[n, c, y + a - 1, x + b - 1]      (zero padding)

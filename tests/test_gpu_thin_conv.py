@@ -117,3 +117,37 @@ def test_cin1_pool_into_a_halo_plane(origin):
     mask = torch.ones_like(plane, dtype=torch.bool)
     mask[:, :, oy:oy + H // 2, ox:ox + W // 2] = False
     assert bool((plane[mask] == 7.0).all())
+
+
+@pytest.mark.parametrize('relu', [True, False])
+@pytest.mark.parametrize('paths', ['both', 'pooled_only', 'full_only'])
+def test_activation_pool_training_form_matches_aten(relu, paths):
+    """_ActPool2x2 (tai_act_maxpool2x2_forward / _backward) against relu + max_pool2d under autograd, on values with many
+    exact ties (quantised, and zeros after the ReLU): the pooled gradient must go to the FIRST maximum of a window."""
+    from video_frame_inpainting_amd import conv_ops
+    g = torch.Generator().manual_seed(3)
+    z = (torch.randint(-3, 4, (3, 5, 12, 24), generator=g).float() * 0.5).cuda().requires_grad_(True)
+    y, yp = conv_ops._ActPool2x2.apply(z, relu)
+    zr = z.detach().clone().requires_grad_(True)
+    yr = torch.relu(zr) if relu else zr
+    ypr = F.max_pool2d(yr, 2)
+    assert torch.equal(y, yr) and torch.equal(yp, ypr)
+    gy = torch.randn(y.shape, generator=g).cuda()
+    gyp = torch.randn(yp.shape, generator=g).cuda()
+    loss = lambda a, b: ((a * gy).sum() if paths != 'pooled_only' else 0) + ((b * gyp).sum() if paths != 'full_only' else 0)
+    loss(y, yp).backward()
+    loss(yr, ypr).backward()
+    assert torch.allclose(z.grad, zr.grad, rtol=0, atol=1e-6), float((z.grad - zr.grad).abs().max())
+
+
+def test_conv_pool_pair_under_autograd_uses_the_fused_form():
+    from video_frame_inpainting_amd import conv_ops
+    torch.manual_seed(5)
+    x = torch.randn(8, 64, 32, 32, device='cuda', requires_grad=True)
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1).cuda()
+    y, yp = conv_ops.conv_bias_act_maxpool(x, conv.weight, conv.bias, 1, 'relu')
+    assert type(yp.grad_fn).__name__ == '_ActPool2x2Backward'
+    ref = torch.relu(F.conv2d(x, conv.weight, conv.bias, padding=1))
+    assert float((y - ref).abs().max()) <= 1e-4 and float((yp - F.max_pool2d(ref, 2)).abs().max()) <= 1e-4
+    (y.mean() + yp.mean()).backward()
+    assert conv.weight.grad is not None and x.grad is not None

@@ -111,6 +111,10 @@ def lib():
     L.tai_conv3x3_wino_wrw.restype = I
     L.tai_conv3x3_wino_wrw_set_paired.argtypes = [I]
     L.tai_conv3x3_wino_wrw_set_paired.restype = I
+    L.tai_act_maxpool2x2_forward.argtypes = [P, P, P, ctypes.c_longlong, I, I, I, V]
+    L.tai_act_maxpool2x2_forward.restype = I
+    L.tai_act_maxpool2x2_backward.argtypes = [P, P, P, P, ctypes.c_longlong, I, I, I, V]
+    L.tai_act_maxpool2x2_backward.restype = I
     L.tai_sn_power_iteration.argtypes = [P, P, P, P, I, I, I, V]
     L.tai_sn_power_iteration.restype = I
     L.tai_conv_shift_stack.argtypes = [P, P, I, I, I, I, I, V]

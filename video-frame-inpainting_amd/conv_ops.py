@@ -368,6 +368,40 @@ class _WinoConvKxK(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class _ActPool2x2(torch.autograd.Function):
+    """(y, max_pool2d(y, 2)) with y = relu(z) or z, under autograd: one pass forward, and ONE pass backward for what ATen
+    runs as max_pool2d backward + the sum of the two gradient paths into y + threshold_backward."""
+
+    @staticmethod
+    def forward(ctx, z, relu):
+        z = z.contiguous()
+        N, C, H, W = z.shape
+        y = torch.empty_like(z)
+        yp = torch.empty((N, C, H // 2, W // 2), dtype=z.dtype, device=z.device)
+        with torch.cuda.device(z.device):
+            _native.check(_native.lib().tai_act_maxpool2x2_forward(z.data_ptr(), y.data_ptr(), yp.data_ptr(), N * C, H, W, int(relu),
+                                                                   torch.cuda.current_stream(z.device).cuda_stream),
+                          'tai_act_maxpool2x2_forward')
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(y)
+        return y, yp
+
+    @staticmethod
+    def backward(ctx, gy, gyp):
+        y, = ctx.saved_tensors
+        N, C, H, W = y.shape
+        gy = gy.contiguous() if gy is not None else None
+        gyp = gyp.contiguous() if gyp is not None else None
+        gz = torch.empty_like(y)
+        with torch.cuda.device(y.device):
+            _native.check(_native.lib().tai_act_maxpool2x2_backward(gy.data_ptr() if gy is not None else None,
+                                                                    gyp.data_ptr() if gyp is not None else None, y.data_ptr(),
+                                                                    gz.data_ptr(), N * C, H, W, int(ctx.relu),
+                                                                    torch.cuda.current_stream(y.device).cuda_stream),
+                          'tai_act_maxpool2x2_backward')
+        return gz, None
+
+
 def conv_bias_act_maxpool(x, weight, bias, padding, act):
     """(y, max_pool2d(y, 2)) with y = conv_bias_act(x, ...): the kernels that own a whole 2x2 window per lane (Winograd,
     one-input-channel) write the pooled tensor in their epilogue instead of leaving a second pass over y to ATen."""
@@ -397,6 +431,11 @@ def conv_bias_act_maxpool(x, weight, bias, padding, act):
                                                                      yp.data_ptr(), N, Ci, Co, H, W, _ACT[act], stream),
                                   'tai_conv3x3_wino_forward_maxpool')
             return y, yp
+    if (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and act in (None, 'relu') and x.shape[2] % 2 == 0
+            and x.shape[3] % 4 == 0 and torch.is_grad_enabled()):
+        # training: the convolution without its activation, then activation + pool as one Function (one backward pass for
+        # the pool's scatter, the sum of the two gradient paths into y and the ReLU mask)
+        return _ActPool2x2.apply(conv_bias_act(x, weight, bias, padding, None), act == 'relu')
     y = conv_bias_act(x, weight, bias, padding, act)
     return y, F.max_pool2d(y, 2)
 

@@ -412,6 +412,29 @@ int tai_sn_power_iteration(float* weight, float* u, float* scratch, float* sigma
     return check_launch("sn_power_iteration");
 }
 
+int tai_act_maxpool2x2_forward(const float* z, float* y, float* ypool, long long planes, int H, int W, int relu, void* hip_stream) {
+    g_err[0] = 0;
+    if (!z || !y || !ypool) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (planes <= 0 || H <= 0 || W <= 0 || H % 2 != 0 || W % 4 != 0) return fail(TAI_SEPCONV_EINVAL, "%s", "act_maxpool2x2: needs even H and W % 4 == 0");
+    const long long work = planes * (H / 2) * (W / 4);
+    const int blocks = (int)((work + 255) / 256 < 16384 ? (work + 255) / 256 : 16384);
+    hipLaunchKernelGGL(bact::act_pool2x2_forward, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), z, y, ypool, planes,
+                       H, W, relu ? 1 : 0);
+    return check_launch("act_maxpool2x2_forward");
+}
+
+int tai_act_maxpool2x2_backward(const float* grad_y, const float* grad_ypool, const float* y, float* grad_z, long long planes, int H,
+                                int W, int relu, void* hip_stream) {
+    g_err[0] = 0;
+    if (!y || !grad_z) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (planes <= 0 || H <= 0 || W <= 0 || H % 2 != 0 || W % 4 != 0) return fail(TAI_SEPCONV_EINVAL, "%s", "act_maxpool2x2: needs even H and W % 4 == 0");
+    const long long work = planes * (H / 2) * (W / 4);
+    const int blocks = (int)((work + 255) / 256 < 16384 ? (work + 255) / 256 : 16384);
+    hipLaunchKernelGGL(bact::act_pool2x2_backward, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), grad_y, grad_ypool,
+                       y, grad_z, planes, H, W, relu ? 1 : 0);
+    return check_launch("act_maxpool2x2_backward");
+}
+
 int tai_conv_shift_stack(const float* x, float* out, int N, int C, int H, int W, int k, void* hip_stream) {
     g_err[0] = 0;
     if (!x || !out) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
