@@ -125,6 +125,11 @@ int tai_act_maxpool2x2_backward(const float* grad_y, const float* grad_ypool, co
 long long tai_conv3x3_wino_wrw_workspace_floats(int N, int C, int K, int H, int W);
 int tai_conv3x3_wino_wrw(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int N, int C, int K, int H,
                          int W, void* hip_stream);
+/* ... with x given as a plane of in_h x in_w per channel whose pixel (in_oy, in_ox) lies under output pixel (0, 0): an input
+ * that carries its own halo (the shifted-copy stack of the 5x5 / 7x7 layers, tai_conv_shift_stack: (H + 2, W + 4, 1, 2)) is
+ * read inside it, zero padding applies outside the plane only.  dw is then the gradient of the blocked 3x3 weight. */
+int tai_conv3x3_wino_wrw_window(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int N, int C, int K,
+                                int H, int W, int in_h, int in_w, int in_oy, int in_ox, void* hip_stream);
 /* Load scheme of the weight-gradient kernel when W % 32 == 0: 1 (default) = chunk pairs over 16 consecutive tiles, whole
  * 128-byte lines per load; 0 = 8-tile chunks as for the other widths (same results, for A/B timing).  Returns the previous value. */
 int tai_conv3x3_wino_wrw_set_paired(int on);

@@ -109,6 +109,8 @@ def lib():
     L.tai_conv3x3_wino_wrw_workspace_floats.restype = ctypes.c_longlong
     L.tai_conv3x3_wino_wrw.argtypes = [P, P, P, P, P, I, I, I, I, I, V]
     L.tai_conv3x3_wino_wrw.restype = I
+    L.tai_conv3x3_wino_wrw_window.argtypes = [P, P, P, P, P] + [I] * 9 + [V]
+    L.tai_conv3x3_wino_wrw_window.restype = I
     L.tai_conv3x3_wino_wrw_set_paired.argtypes = [I]
     L.tai_conv3x3_wino_wrw_set_paired.restype = I
     L.tai_act_maxpool2x2_forward.argtypes = [P, P, P, ctypes.c_longlong, I, I, I, V]

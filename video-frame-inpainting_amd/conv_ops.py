@@ -98,7 +98,7 @@ def _wino_weights_kxk(weight, transposed=False):
     return _cached(weight, ('wino_kxk', transposed), make)
 
 
-def _kxk_as_wino(x, weight, bias, act, pool, transposed=False):
+def _kxk_as_wino(x, weight, bias, act, pool, transposed=False, keep_stack=False):
     """5x5 / 7x7 "same" convolution as the Winograd 3x3 kernel over S*S shifted copies of the input (csrc/thin_conv.hip.inc,
     shift_stack): 1.56x / 1.36x fewer multiplies than the direct form MIOpen runs.  Returns y or (y, pooled).
     ``transposed``: convolve with the transposed and flipped filter (the input gradient of the same layer)."""
@@ -117,7 +117,16 @@ def _kxk_as_wino(x, weight, bias, act, pool, transposed=False):
         _native.check(L.tai_conv3x3_wino_forward_window(stack.data_ptr(), U.data_ptr(), bias.data_ptr(), y.data_ptr(),
                                                         yp.data_ptr() if pool else None, N, S * S * C, K, H, W, H + 2, W + 4,
                                                         1, 2, _ACT[act], stream), 'tai_conv3x3_wino_forward_window')
+    if keep_stack:
+        return y, stack
     return (y, yp) if pool else y
+
+
+def _unblock3x3_weight(wb, C, k):
+    """Inverse of _block3x3_weight for a gradient: [K, S*S*C, 3, 3] -> [K, C, k, k] (the taps past k are padding)."""
+    K = wb.shape[0]
+    S = (k + 2) // 3
+    return wb.view(K, S, S, C, 3, 3).permute(0, 3, 1, 4, 2, 5).reshape(K, C, 3 * S, 3 * S)[:, :, :k, :k].contiguous()
 
 
 _HALO_PLANES = {}
@@ -263,17 +272,18 @@ def _wino_launch(x, U, bias, N, Ci, Co, H, W, act):
 _WRW_WORKSPACE = {}
 
 
-def wino_weight_grad(x, grad_out, with_bias=False):
+def wino_weight_grad(x, grad_out, with_bias=False, window=None):
     """dL/dw [Co, Ci, 3, 3] of y = conv2d(x, w, padding=1) from x [N, Ci, H, W] and dL/dy [N, Co, H, W], by
     ``tai_conv3x3_wino_wrw`` (Winograd-domain weight gradient on the fp32 MFMA pipe); None if the shape is not supported
     (odd H, W not a multiple of 16, a tensor of 2 GiB or more).  ``with_bias``: returns (dw, dbias), the bias gradient
-    summed by the same kernel.  The workspace (partial sums per workgroup) is kept per device and grows to the largest
-    request."""
-    N, Ci, H, W = x.shape
-    Co = grad_out.shape[1]
+    summed by the same kernel.  ``window`` = (in_oy, in_ox): x is a plane [N, Ci, in_h, in_w] that carries its own halo,
+    with the pixel under output (0, 0) at (in_oy, in_ox) (the shifted-copy stack of the 5x5 / 7x7 layers).  The workspace
+    (partial sums per workgroup) is kept per device and grows to the largest request."""
+    N, Ci = x.shape[0], x.shape[1]
+    Co, H, W = grad_out.shape[1], grad_out.shape[2], grad_out.shape[3]
     L = _native.lib()
     floats = L.tai_conv3x3_wino_wrw_workspace_floats(N, Ci, Co, H, W)
-    if floats < 0:
+    if floats < 0 or N * Ci * x.shape[2] * x.shape[3] >= 2 ** 29:
         return None
     ws = _WRW_WORKSPACE.get(x.device)
     if ws is None or ws.numel() < floats:
@@ -281,9 +291,15 @@ def wino_weight_grad(x, grad_out, with_bias=False):
     dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=x.device)
     db = torch.empty(Co, dtype=torch.float32, device=x.device) if with_bias else None
     with torch.cuda.device(x.device):
-        _native.check(L.tai_conv3x3_wino_wrw(x.data_ptr(), grad_out.data_ptr(), dw.data_ptr(), db.data_ptr() if with_bias else None,
-                                             ws.data_ptr(), N, Ci, Co, H, W, torch.cuda.current_stream(x.device).cuda_stream),
-                      'tai_conv3x3_wino_wrw')
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        if window is None:
+            _native.check(L.tai_conv3x3_wino_wrw(x.data_ptr(), grad_out.data_ptr(), dw.data_ptr(), db.data_ptr() if with_bias else None,
+                                                 ws.data_ptr(), N, Ci, Co, H, W, stream), 'tai_conv3x3_wino_wrw')
+        else:
+            _native.check(L.tai_conv3x3_wino_wrw_window(x.data_ptr(), grad_out.data_ptr(), dw.data_ptr(),
+                                                        db.data_ptr() if with_bias else None, ws.data_ptr(), N, Ci, Co, H, W,
+                                                        x.shape[2], x.shape[3], window[0], window[1], stream),
+                          'tai_conv3x3_wino_wrw_window')
     return (dw, db) if with_bias else dw
 
 
@@ -338,19 +354,21 @@ class _WinoConv3x3(torch.autograd.Function):
 
 class _WinoConvKxK(torch.autograd.Function):
     """Training form of the 5x5 / 7x7 convolutions (MotionEnc, mcnet.py:36-47): forward and input gradient as 3x3 blocks on
-    the Winograd-MFMA kernel (_kxk_as_wino), weight gradient from MIOpen."""
+    the Winograd-MFMA kernel (_kxk_as_wino), weight and bias gradients on the Winograd-domain weight-gradient kernel over the
+    same stack of shifted copies (MIOpen's where that kernel does not take the shape)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act):
         x = x.contiguous()
-        y = _kxk_as_wino(x, weight, bias, act, False)
+        y, stack = _kxk_as_wino(x, weight, bias, act, False, keep_stack=True)
         ctx.act = act
-        ctx.save_for_backward(x, weight, y if act is not None else None)
+        # the stack of shifted copies (S*S times the input) is kept for the weight gradient: 134 / 151 MB per MotionEnc call
+        ctx.save_for_backward(x, weight, y if act is not None else None, stack)
         return y
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, weight, y = ctx.saved_tensors
+        x, weight, y, stack = ctx.saved_tensors
         g = grad_out.contiguous()
         if ctx.act == 'relu':
             g = torch.ops.aten.threshold_backward(g, y, 0)
@@ -361,9 +379,14 @@ class _WinoConvKxK(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _kxk_as_wino(g, weight, torch.zeros(Ci, dtype=g.dtype, device=g.device), None, False, transposed=True)
         if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(g, x, weight, [Co], [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
-        if ctx.needs_input_grad[2]:
+            # the weight gradient of the blocked 3x3 form over the stack (it carries its halo: origin (1, 2)), then un-blocked
+            both = wino_weight_grad(stack, g, with_bias=True, window=(1, 2))
+            if both is not None:
+                gw, gb = _unblock3x3_weight(both[0], Ci, k), both[1]
+            else:
+                gw = torch.ops.aten.convolution_backward(g, x, weight, [Co], [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
+        if ctx.needs_input_grad[2] and gb is None:
             gb = g.sum((0, 2, 3))
         return gx, gw, gb, None
 

@@ -481,9 +481,10 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
 
 // Split of the weight-gradient kernel's reduction (the tiles) over workgroups: about one workgroup per CU in total.
 struct WrwPlan { int kblocks, cblocks, nchunks, chunks_per_split, splits, pair; };
-static bool wrw_plan(int N, int C, int K, int H, int W, WrwPlan& p) {
+static bool wrw_plan(int N, int C, int K, int H, int W, WrwPlan& p, int in_h = 0, int in_w = 0) {
     if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || H % 2 != 0 || W % 16 != 0) return false;
-    if ((long long)N * C * H * W * 4 >= (1LL << 31) || (long long)N * K * H * W * 4 >= (1LL << 31)) return false;
+    if (in_h <= 0) { in_h = H; in_w = W; }
+    if ((long long)N * C * in_h * in_w * 4 >= (1LL << 31) || (long long)N * K * H * W * 4 >= (1LL << 31)) return false;
     p.kblocks = (K + 63) / 64;
     p.cblocks = (C + 63) / 64;
     p.nchunks = (int)((long long)N * (H / 2) * (W / 2) / wino::wrw::CT);
@@ -507,11 +508,16 @@ static std::atomic<int> g_wrw_pair{1};              // 1: paired chunks (whole-l
 int tai_conv3x3_wino_wrw_set_paired(int on) { return g_wrw_pair.exchange(on ? 1 : 0, std::memory_order_relaxed); }
 
 static int wino_wrw_impl(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int N, int C, int K, int H,
-                         int W, void* hip_stream, long long* stamps) {
+                         int W, void* hip_stream, long long* stamps, int in_h = 0, int in_w = 0, int in_oy = 0, int in_ox = 0) {
     g_err[0] = 0;
     if (!x || !dy || !dw || !workspace) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
     WrwPlan p;
-    if (!wrw_plan(N, C, K, H, W, p))
+    if (in_h <= 0) { in_h = H; in_w = W; in_oy = in_ox = 0; }
+    // the window of every tile must lie inside the plane or in its zero padding on all sides consistently: the origin may
+    // not be negative and an input with a halo (origin > 0) must hold the whole 1-pixel frame
+    if (in_oy < 0 || in_ox < 0 || in_oy + H > in_h || in_ox + W > in_w)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_wrw: output window outside the input plane");
+    if (!wrw_plan(N, C, K, H, W, p, in_h, in_w))
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_wrw: needs even H, W % 16 == 0 and tensors below 2 GiB");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const int grid = p.kblocks * p.cblocks * p.splits;
@@ -521,7 +527,7 @@ static int wino_wrw_impl(const float* x, const float* dy, float* dw, float* dbia
         auto kern = wino::wrw::conv3x3_wrw<D, P>;                                                                              \
         if (int rc = allow_lds(kern, wino::wrw::LDS_BYTES)) return rc;                                                         \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), wino::wrw::LDS_BYTES, stream, x, dy, workspace, wsb, N, C, K, H, W,   \
-                           p.kblocks, p.cblocks, p.chunks_per_split, p.nchunks, stamps);                                       \
+                           in_h, in_w, in_oy, in_ox, p.kblocks, p.cblocks, p.chunks_per_split, p.nchunks, stamps);                                             \
     } while (0)
     const bool pair = p.pair && g_wrw_pair.load(std::memory_order_relaxed);
     if (stamps) { if (pair) TAI_LAUNCH_WRW(2, true); else TAI_LAUNCH_WRW(2, false); }
@@ -538,6 +544,12 @@ static int wino_wrw_impl(const float* x, const float* dy, float* dw, float* dbia
 int tai_conv3x3_wino_wrw(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int N, int C, int K, int H,
                          int W, void* hip_stream) {
     return wino_wrw_impl(x, dy, dw, dbias, workspace, N, C, K, H, W, hip_stream, nullptr);
+}
+
+int tai_conv3x3_wino_wrw_window(const float* x, const float* dy, float* dw, float* dbias, float* workspace, int N, int C, int K,
+                                int H, int W, int in_h, int in_w, int in_oy, int in_ox, void* hip_stream) {
+    if (in_h <= 0 || in_w <= 0) { g_err[0] = 0; return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_wrw_window: bad plane"); }
+    return wino_wrw_impl(x, dy, dw, dbias, workspace, N, C, K, H, W, hip_stream, nullptr, in_h, in_w, in_oy, in_ox);
 }
 
 #ifdef TAI_TIMING_VARIANTS
