@@ -53,3 +53,27 @@ def test_counted_waits_match_the_loads_behind_the_last_dma(device_asm, parts, ta
         for s in dma_segs[1:3]:
             assert not any(re.search(r'\bscratch_(load|store)', l) for l in s), name
     assert found == 1
+
+
+@pytest.mark.parametrize('pair', [0, 1])
+def test_weight_gradient_chunk_loop_keeps_its_accumulators_in_place(device_asm, pair):
+    """The weight-gradient kernel's chunk loop (csrc/wino_wrw.hip.inc) must be one basic block of 128 MFMAs with no spill and
+    no accumulator traffic: with branches in the tile-position update the register allocator once copied all 256
+    accumulator registers through scratch and VGPRs on every iteration (2x the kernel time) -- a property
+    of the generated code, so it is checked on the generated code."""
+    prefix = '_ZN4wino3wrw11conv3x3_wrwILi0ELb%dEE' % pair
+    found = 0
+    for name, lines in _kernel_bodies(device_asm, prefix):
+        found += 1
+        mfma = [n for n, l in enumerate(lines) if 'v_mfma_f32_32x32x2_f32' in l]
+        assert len(mfma) == 128, (name, len(mfma))               # two chunk bodies, nothing peeled or duplicated
+        loop = lines[mfma[0]:mfma[-1] + 1]
+        assert not any(re.search(r'\bscratch_(load|store)', l) for l in loop), name
+        assert not any(re.search(r'\bv_accvgpr_(read|write|mov)', l) for l in loop), name
+        labels = [l for l in loop if re.match(r'^\.LBB\w+:', l.strip())]
+        assert not labels, (name, labels)                        # no block boundary between the first and the last MFMA
+        assert sum(1 for l in loop if 's_barrier' in l) == 1     # (the second chunk's barrier follows its last MFMA)
+        # whole-line loads in the paired form: 12 x 16-byte loads per pair of chunks, none in the plain form
+        wide = sum(1 for l in loop if 'buffer_load_dwordx4' in l)
+        assert wide == (12 if pair else 0), (name, wide)
+    assert found == 1
