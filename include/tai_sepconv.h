@@ -105,6 +105,14 @@ int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float*
  * 45-47).  W % 4 == 0. */
 int tai_conv_shift_stack(const float* x, float* out, int N, int C, int H, int W, int k, void* hip_stream);
 
+/* Weight and bias gradients of the thin layers (tai_conv_cin1_forward / tai_conv_cout1_3x3_forward under loss.backward()):
+ *   dw[cb][a][b] = sum over n, y, x of big[n, cb, y, x] * thin[n, 0, y + a - k/2, x + b - k/2]  (zero padding),  dbias[cb] = sum of big[n, cb]
+ * big [N, Cb, H, W], thin [N, 1, H, W] fp32 contiguous, W % 4 == 0, k in {3, 5}; dw [Cb, k, k] or dbias [Cb] may be NULL;
+ * workspace: N * Cb * 32 floats.  One-input-channel convolution: big = dL/dy, thin = x.  One-output-channel convolution:
+ * big = x, thin = dL/dy, and dw[c][a][b] is the gradient of weight[0][c][k-1-a][k-1-b].  Reproducible (fixed summation order). */
+int tai_thin_conv_wrw(const float* big, const float* thin, float* dw, float* dbias, float* workspace, int N, int Cb, int H, int W,
+                      int k, void* hip_stream);
+
 /* Activation + 2x2 max pool behind a convolution, training form (nn.ReLU + nn.MaxPool2d(2) of ContentEnc / MotionEnc,
  * src/models/mcnet/mcnet.py:28-60, 79-118): z, y [planes, H, W], ypool [planes, H/2, W/2] fp32 contiguous, H even, W % 4 == 0.
  *   forward:  y = relu ? max(z, 0) : z;  ypool = max over each 2x2 window of y                     (y may alias z)

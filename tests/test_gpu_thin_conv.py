@@ -151,3 +151,50 @@ def test_conv_pool_pair_under_autograd_uses_the_fused_form():
     assert float((y - ref).abs().max()) <= 1e-4 and float((yp - F.max_pool2d(ref, 2)).abs().max()) <= 1e-4
     (y.mean() + yp.mean()).backward()
     assert conv.weight.grad is not None and x.grad is not None
+
+
+@pytest.mark.parametrize('k,act', [(5, 'relu'), (3, 'relu'), (3, None)])
+def test_one_input_channel_layer_training_form(k, act):
+    """nn.Conv2d(1, gf, k) (+ ReLU) under autograd: forward on tai_conv_cin1_forward, weight / bias gradients from
+    tai_thin_conv_wrw, against fp64 autograd of conv2d."""
+    from video_frame_inpainting_amd import conv_ops
+    g = torch.Generator().manual_seed(k)
+    N, Co, H, W = 6, 64, 24, 40
+    x = torch.randn(N, 1, H, W, generator=g).cuda()
+    w = (torch.randn(Co, 1, k, k, generator=g) * 0.2).cuda().requires_grad_(True)
+    b = torch.randn(Co, generator=g).cuda().requires_grad_(True)
+    go = torch.randn(N, Co, H, W, generator=g).cuda()
+    y = conv_ops.conv_bias_act(x, w, b, k // 2, act)
+    assert type(y.grad_fn).__name__ == '_ThinInConvBackward'
+    gw, gb = torch.autograd.grad(y, (w, b), go)
+    wd, bd = w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    yd = F.conv2d(x.double(), wd, bd, padding=k // 2)
+    yd = yd * (y.detach() > 0) if act == 'relu' else yd
+    rw, rb = torch.autograd.grad(yd, (wd, bd), go.double())
+    assert float((y.double() - yd).abs().max()) <= 1e-5
+    for got, ref in ((gw, rw), (gb, rb)):
+        assert float((got.double() - ref).abs().max()) <= 1e-4 * (1 + float(ref.abs().max()))
+    assert torch.equal(torch.autograd.grad(conv_ops.conv_bias_act(x, w, b, k // 2, act), w, go)[0], gw)      # reproducible
+
+
+@pytest.mark.parametrize('transposed', [True, False])
+def test_one_output_channel_layer_training_form(transposed):
+    """nn.ConvTranspose2d(gf, 1, 3, padding=1) + Tanh (mcnet.py:223-224) under autograd: input, weight and bias gradients
+    against fp64 autograd of the reference ops."""
+    from video_frame_inpainting_amd import conv_ops
+    g = torch.Generator().manual_seed(9)
+    N, Ci, H, W = 5, 64, 20, 36
+    x = torch.randn(N, Ci, H, W, generator=g).cuda().requires_grad_(True)
+    wshape = (Ci, 1, 3, 3) if transposed else (1, Ci, 3, 3)
+    w = (torch.randn(*wshape, generator=g) * 0.1).cuda().requires_grad_(True)
+    b = torch.randn(1, generator=g).cuda().requires_grad_(True)
+    go = torch.randn(N, 1, H, W, generator=g).cuda()
+    y = conv_ops.conv_bias_act(x, w, b, 1, 'tanh', transposed=transposed)
+    assert type(y.grad_fn).__name__ == '_ThinOutConvBackward'
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), go)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yd = torch.tanh(F.conv_transpose2d(xd, wd, bd, padding=1) if transposed else F.conv2d(xd, wd, bd, padding=1))
+    rx, rw, rb = torch.autograd.grad(yd, (xd, wd, bd), go.double())
+    assert float((y.double() - yd).abs().max()) <= 1e-5
+    for got, ref in ((gx, rx), (gw, rw), (gb, rb)):
+        assert float((got.double() - ref).abs().max()) <= 1e-4 * (1 + float(ref.abs().max()))

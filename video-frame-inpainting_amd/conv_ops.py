@@ -391,6 +391,109 @@ class _WinoConvKxK(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+_THIN_WORKSPACE = {}
+
+
+def thin_weight_grad(big, thin, k):
+    """(dw [Cb, k, k], db [Cb]) with dw[cb][a][b] = sum of big[n, cb, y, x] * thin[n, 0, y + a - k/2, x + b - k/2] and
+    db[cb] = sum of big[n, cb]: one pass over ``big`` (tai_thin_conv_wrw)."""
+    N, Cb, H, W = big.shape
+    ws = _THIN_WORKSPACE.get(big.device)
+    if ws is None or ws.numel() < N * Cb * 32:
+        ws = _THIN_WORKSPACE[big.device] = torch.empty(N * Cb * 32, dtype=torch.float32, device=big.device)
+    dw = torch.empty((Cb, k, k), dtype=torch.float32, device=big.device)
+    db = torch.empty(Cb, dtype=torch.float32, device=big.device)
+    with torch.cuda.device(big.device):
+        _native.check(_native.lib().tai_thin_conv_wrw(big.data_ptr(), thin.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                                      N, Cb, H, W, k, torch.cuda.current_stream(big.device).cuda_stream),
+                      'tai_thin_conv_wrw')
+    return dw, db
+
+
+class _ThinInConv(torch.autograd.Function):
+    """Training form of the one-input-channel layers (nn.Conv2d(1, gf, k) + ReLU, mcnet.py:28-31, 79-81): forward on
+    tai_conv_cin1_forward, weight and bias gradients in one pass over the output gradient (thin_weight_grad); the input is
+    a frame (difference), which needs no gradient -- if it does, ATen's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x = x.contiguous()
+        N, _, H, W = x.shape
+        Co, k = weight.shape[0], weight.shape[2]
+        y = torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _native.check(_native.lib().tai_conv_cin1_forward(x.data_ptr(), weight.detach().contiguous().data_ptr(), bias.data_ptr(),
+                                                              y.data_ptr(), N, Co, H, W, k, _ACT[act],
+                                                              torch.cuda.current_stream(x.device).cuda_stream), 'tai_conv_cin1_forward')
+        ctx.act = act
+        ctx.save_for_backward(x, weight, y if act is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, y = ctx.saved_tensors
+        g = grad_out.contiguous()
+        if ctx.act == 'relu':
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        Co, k = weight.shape[0], weight.shape[2]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(g, x, weight, [Co], [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw, gb = thin_weight_grad(g, x, k)
+            gw = dw.view_as(weight)
+        return gx, gw, gb, None
+
+
+class _ThinOutConv(torch.autograd.Function):
+    """Training form of the one-output-channel layer (nn.ConvTranspose2d(gf, 1, 3, padding=1) + Tanh, mcnet.py:223-224):
+    forward on tai_conv_cout1_3x3_forward; the input gradient is a one-input-channel convolution of the output gradient
+    with the flipped filter (tai_conv_cin1_forward), the weight gradient one pass over the input (thin_weight_grad)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, transposed):
+        x = x.contiguous()
+        N, Ci, H, W = x.shape
+        wd = _cached(weight, ('direct', transposed), lambda: _as_conv_weight(weight.detach(), transposed).contiguous())   # [1, Ci, 3, 3]
+        y = torch.empty((N, 1, H, W), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _native.check(_native.lib().tai_conv_cout1_3x3_forward(x.data_ptr(), wd.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci,
+                                                                   H, W, _ACT[act], torch.cuda.current_stream(x.device).cuda_stream),
+                          'tai_conv_cout1_3x3_forward')
+        ctx.act, ctx.transposed = act, transposed
+        ctx.save_for_backward(x, weight, y if act is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, y = ctx.saved_tensors
+        g = grad_out.contiguous()
+        if ctx.act == 'relu':
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        elif ctx.act == 'tanh':
+            g = g * (1 - y * y)
+        N, Ci, H, W = x.shape
+        wd = _cached(weight, ('direct', ctx.transposed), lambda: _as_conv_weight(weight.detach(), ctx.transposed).contiguous())
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            # d/dx_c of sum_c conv(x_c, wd[0, c]) is conv(g, wd[0, c] flipped): Ci output channels from the one-channel g
+            wf = wd.flip(2, 3).transpose(0, 1).contiguous()                           # [Ci, 1, 3, 3]
+            gx = torch.empty_like(x)
+            zero = torch.zeros(Ci, dtype=x.dtype, device=x.device)
+            with torch.cuda.device(x.device):
+                _native.check(_native.lib().tai_conv_cin1_forward(g.data_ptr(), wf.data_ptr(), zero.data_ptr(), gx.data_ptr(), N, Ci, H,
+                                                                  W, 3, 0, torch.cuda.current_stream(x.device).cuda_stream),
+                              'tai_conv_cin1_forward')
+        if ctx.needs_input_grad[1]:
+            # dwd[0][c][a][b] = sum g[y, x] x_c[y + a - 1, x + b - 1] = thin_weight_grad(x, g)[c][2 - a][2 - b]
+            dwd = thin_weight_grad(x, g, 3)[0].flip(1, 2).unsqueeze(0)               # [1, Ci, 3, 3] in conv2d layout
+            gw = _as_conv_weight(dwd, ctx.transposed).contiguous().view_as(weight)
+        if ctx.needs_input_grad[2]:
+            gb = g.sum().view(1)
+        return gx, gw, gb, None, None
+
+
 class _ActPool2x2(torch.autograd.Function):
     """(y, max_pool2d(y, 2)) with y = relu(z) or z, under autograd: one pass forward, and ONE pass backward for what ATen
     runs as max_pool2d backward + the sum of the two gradient paths into y + threshold_backward."""
@@ -514,6 +617,13 @@ def _conv_bias_act(x, weight, bias, padding, act, transposed, out):
             N, _, H, W = x.shape
             if _kxk_ok(N, Ci, Co, H, W, k, k, padding) and _kxk_ok(N, Co, Ci, H, W, k, k, padding):
                 return _WinoConvKxK.apply(x, weight, bias, act)
+        if x.is_cuda and x.dtype == torch.float32 and bias is not None and x.shape[3] % 4 == 0 and weight.shape[2] == weight.shape[3]:
+            Co, Ci = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
+            k = weight.shape[2]
+            if Ci == 1 and not transposed and k in (3, 5) and padding == k // 2 and act in (None, 'relu') and Co >= 16:
+                return _ThinInConv.apply(x, weight, bias, act)
+            if Co == 1 and k == 3 and padding == 1 and Ci >= 16:
+                return _ThinOutConv.apply(x, weight, bias, act, transposed)
         y = F.conv2d(x, _as_conv_weight(weight, transposed), bias, stride=1, padding=padding)
         return torch.relu(y) if act == 'relu' else (torch.tanh(y) if act == 'tanh' else y)
     kh, kw = weight.shape[2], weight.shape[3]

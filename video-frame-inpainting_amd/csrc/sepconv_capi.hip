@@ -412,6 +412,21 @@ int tai_sn_power_iteration(float* weight, float* u, float* scratch, float* sigma
     return check_launch("sn_power_iteration");
 }
 
+int tai_thin_conv_wrw(const float* big, const float* thin, float* dw, float* dbias, float* workspace, int N, int Cb, int H, int W,
+                      int k, void* hip_stream) {
+    g_err[0] = 0;
+    if (!big || !thin || !workspace || (!dw && !dbias)) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (N <= 0 || Cb <= 0 || H <= 0 || W <= 0 || W % 4 != 0 || (k != 3 && k != 5) || (long long)N * Cb > 0x7fffffffLL)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "thin_conv_wrw: needs W % 4 == 0 and k in {3, 5}");
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (k == 3) hipLaunchKernelGGL(thin::thin_wrw<3>, dim3(N * Cb), dim3(256), 0, stream, big, thin, workspace, N, Cb, H, W);
+    else hipLaunchKernelGGL(thin::thin_wrw<5>, dim3(N * Cb), dim3(256), 0, stream, big, thin, workspace, N, Cb, H, W);
+    if (int rc = check_launch("thin_conv_wrw")) return rc;
+    const int total = Cb * (k * k + 1);
+    hipLaunchKernelGGL(thin::thin_wrw_reduce, dim3((total + 255) / 256), dim3(256), 0, stream, workspace, dw, dbias, N, Cb, k * k);
+    return check_launch("thin_conv_wrw_reduce");
+}
+
 int tai_act_maxpool2x2_forward(const float* z, float* y, float* ypool, long long planes, int H, int W, int relu, void* hip_stream) {
     g_err[0] = 0;
     if (!z || !y || !ypool) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
