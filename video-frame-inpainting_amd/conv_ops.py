@@ -269,6 +269,20 @@ def _wino_launch(x, U, bias, N, Ci, Co, H, W, act):
     return y
 
 
+_ZERO_BIAS = {}
+
+
+def _zero_bias(n, device):
+    """A cached all-zero fp32 bias (read-only) for the input-gradient convolutions: one fill kernel per call otherwise."""
+    key = (n, device)
+    z = _ZERO_BIAS.get(key)
+    if z is None:
+        z = torch.zeros(n, dtype=torch.float32, device=device)
+        if not torch.cuda.is_current_stream_capturing():       # (a fill recorded into a graph has not run yet: do not keep it)
+            _ZERO_BIAS[key] = z
+    return z
+
+
 _WRW_WORKSPACE = {}
 
 
@@ -325,13 +339,13 @@ class _WinoConv3x3(torch.autograd.Function):
         if ctx.act == 'relu':
             g = torch.ops.aten.threshold_backward(g, y, 0)        # g where y > 0, else 0: one kernel
         elif ctx.act == 'tanh':
-            g = g * (1 - y * y)
+            g = torch.ops.aten.tanh_backward(g, y)                  # g * (1 - y^2): one kernel
         N, Ci, H, W = x.shape
         Co = g.shape[1]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             # d/dx of conv(x, w_eff) is conv(g, w_eff transposed and flipped): the other orientation of the same weight
-            zero = torch.zeros(Ci, dtype=g.dtype, device=g.device)
+            zero = _zero_bias(Ci, g.device)
             gx = _wino_launch(g, _wino_weights(weight, not ctx.transposed), zero, N, Co, Ci, H, W, None)
         if ctx.needs_input_grad[1]:
             gw_eff = None
@@ -373,11 +387,11 @@ class _WinoConvKxK(torch.autograd.Function):
         if ctx.act == 'relu':
             g = torch.ops.aten.threshold_backward(g, y, 0)
         elif ctx.act == 'tanh':
-            g = g * (1 - y * y)
+            g = torch.ops.aten.tanh_backward(g, y)                  # g * (1 - y^2): one kernel
         Co, Ci, k = weight.shape[0], weight.shape[1], weight.shape[2]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _kxk_as_wino(g, weight, torch.zeros(Ci, dtype=g.dtype, device=g.device), None, False, transposed=True)
+            gx = _kxk_as_wino(g, weight, _zero_bias(Ci, g.device), None, False, transposed=True)
         if ctx.needs_input_grad[1]:
             # the weight gradient of the blocked 3x3 form over the stack (it carries its halo: origin (1, 2)), then un-blocked
             both = wino_weight_grad(stack, g, with_bias=True, window=(1, 2))
@@ -472,7 +486,7 @@ class _ThinOutConv(torch.autograd.Function):
         if ctx.act == 'relu':
             g = torch.ops.aten.threshold_backward(g, y, 0)
         elif ctx.act == 'tanh':
-            g = g * (1 - y * y)
+            g = torch.ops.aten.tanh_backward(g, y)                  # g * (1 - y^2): one kernel
         N, Ci, H, W = x.shape
         wd = _cached(weight, ('direct', ctx.transposed), lambda: _as_conv_weight(weight.detach(), ctx.transposed).contiguous())
         gx = gw = gb = None
@@ -480,7 +494,7 @@ class _ThinOutConv(torch.autograd.Function):
             # d/dx_c of sum_c conv(x_c, wd[0, c]) is conv(g, wd[0, c] flipped): Ci output channels from the one-channel g
             wf = wd.flip(2, 3).transpose(0, 1).contiguous()                           # [Ci, 1, 3, 3]
             gx = torch.empty_like(x)
-            zero = torch.zeros(Ci, dtype=x.dtype, device=x.device)
+            zero = _zero_bias(Ci, x.device)
             with torch.cuda.device(x.device):
                 _native.check(_native.lib().tai_conv_cin1_forward(g.data_ptr(), wf.data_ptr(), zero.data_ptr(), gx.data_ptr(), N, Ci, H,
                                                                   W, 3, 0, torch.cuda.current_stream(x.device).cuda_stream),
