@@ -60,6 +60,9 @@ int tai_sepconv_backward(const float* grad_output, const float* input, const flo
  * (src/models/tai/tai.py:283,337,343; torch 0.3.1 semantics = align_corners=True), same caller-allocates / asynchronous-
  * on-stream conventions as above. */
 int tai_upsample_bilinear2x_forward(const float* input, float* output, int planes, int H, int W, void* hip_stream);
+/* Its gradient: grad_output [planes, 2H, 2W] -> grad_input [planes, H, W] (every element written), as a gather with the
+ * forward's weights; sums in a fixed order (ATen's backward scatters with atomics). */
+int tai_upsample_bilinear2x_backward(const float* grad_output, float* grad_input, int planes, int H, int W, void* hip_stream);
 
 /* In-place x[n,c,:] = act(x[n,c,:] + bias[c]) over a contiguous fp32 [N, C, HW] tensor; act: 0 none, 1 ReLU, 2 tanh.
  * Finishes the bias-free MIOpen convolutions of the generator in one pass (the reference's nn.Conv2d + nn.ReLU / nn.Tanh

@@ -26,13 +26,21 @@ def test_matches_aten(shape):
     assert float((got.cpu() - want).abs().max()) <= (2e-6 if shape[2] >= 2 and shape[3] >= 2 else 5e-5)
 
 
-def test_backward_matches_aten():
-    x = torch.randn(2, 3, 6, 8, generator=torch.Generator().manual_seed(2)).cuda().requires_grad_()
-    g = torch.randn(2, 3, 12, 16, generator=torch.Generator().manual_seed(3)).cuda()
+@pytest.mark.parametrize('shape', [(2, 3, 6, 8), (1, 2, 1, 1), (2, 2, 1, 5), (1, 3, 2, 2), (3, 5, 7, 9), (2, 51, 64, 64), (1, 4, 33, 130)])
+def test_backward_matches_aten(shape):
+    """The gather form of the gradient (tai_upsample_bilinear2x_backward) against ATen's scatter, and against the fp64
+    adjoint (sum of the gradient = sum of the output gradient: the forward's weights of an output pixel add up to 1)."""
+    B, C, H, W = shape
+    x = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(2)).cuda().requires_grad_()
+    g = torch.randn(B, C, 2 * H, 2 * W, generator=torch.Generator().manual_seed(3)).cuda()
     upsample2x(x).backward(g)
-    x2 = x.detach().clone().requires_grad_()
-    F.interpolate(x2, scale_factor=2, mode='bilinear', align_corners=True).backward(g)
-    assert float((x.grad - x2.grad).abs().max()) <= 1e-5
+    x2 = x.detach().clone().double().requires_grad_()
+    F.interpolate(x2, scale_factor=2, mode='bilinear', align_corners=True).backward(g.double())
+    assert float((x.grad.double() - x2.grad).abs().max()) <= 2e-5
+    assert abs(float(x.grad.double().sum() - g.double().sum())) <= 1e-3 * (1 + float(g.double().abs().sum()) * 1e-3)
+    x3 = x.detach().clone().requires_grad_()
+    upsample2x(x3).backward(g)
+    assert torch.equal(x3.grad, x.grad)                        # fixed summation order
 
 
 @pytest.mark.parametrize('act', [None, 'relu', 'tanh'])

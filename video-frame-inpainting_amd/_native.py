@@ -77,6 +77,8 @@ def lib():
     L.tai_sepconv_backward.restype = I
     L.tai_upsample_bilinear2x_forward.argtypes = [P, P, I, I, I, V]
     L.tai_upsample_bilinear2x_forward.restype = I
+    L.tai_upsample_bilinear2x_backward.argtypes = [P, P, I, I, I, V]
+    L.tai_upsample_bilinear2x_backward.restype = I
     L.tai_conv3x3_wino_weight_floats.argtypes = [I, I]
     L.tai_conv3x3_wino_weight_floats.restype = ctypes.c_longlong
     L.tai_conv3x3_wino_transform_weights.argtypes = [P, P, I, I, V]

@@ -760,6 +760,19 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
     return check_launch("conv3x3_wino");
 }
 
+int tai_upsample_bilinear2x_backward(const float* grad_output, float* grad_input, int planes, int H, int W, void* hip_stream) {
+    g_err[0] = 0;
+    if (!grad_output || !grad_input) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (planes <= 0 || H <= 0 || W <= 0) return fail(TAI_SEPCONV_EINVAL, "%s", "bad dimensions");
+    const float rh = (2 * H > 1) ? (float)(H - 1) / (float)(2 * H - 1) : 0.f;
+    const float rw = (2 * W > 1) ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
+    const long long work = (long long)planes * H * ((W + 3) / 4);
+    const int blocks = (int)((work + 255) / 256 < 65536 ? (work + 255) / 256 : 65536);
+    hipLaunchKernelGGL(ups::upsample2x_align_corners_backward, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                       grad_output, grad_input, planes, H, W, rh, rw);
+    return check_launch("upsample_bilinear2x_backward");
+}
+
 int tai_upsample_bilinear2x_forward(const float* input, float* output, int planes, int H, int W, void* hip_stream) {
     g_err[0] = 0;
     if (!input || !output) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");

@@ -1,6 +1,6 @@
 """Bilinear x2 upsampling (align_corners=True: the reference's torch-0.3.1 ``nn.Upsample(scale_factor=2,
-mode='bilinear')``, tai.py:283,337,343) on the HIP kernel of the C ABI.  The backward pass is ATen's
-``upsample_bilinear2d_backward`` (training only; the forward is what the inference path streams eight times per frame).
+mode='bilinear')``, tai.py:283,337,343) on the HIP kernels of the C ABI (the backward pass as a gather with the forward's
+weights: training only; the forward is what the inference path streams eight times per frame).
 CPU tensors take the stock ATen path: this op, unlike the separable convolution, exists on the CPU in the reference's
 framework too, and host-side tests of the model's control flow run there."""
 import torch
@@ -25,8 +25,13 @@ class _Upsample2xAlignCorners(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         B, C, H, W = ctx.in_shape
-        return torch.ops.aten.upsample_bilinear2d_backward(grad_out.contiguous(), [2 * H, 2 * W], [B, C, H, W], True,
-                                                           None, None)
+        g = grad_out.contiguous()
+        gin = torch.empty((B, C, H, W), dtype=g.dtype, device=g.device)
+        with torch.cuda.device(g.device):
+            _native.check(_native.lib().tai_upsample_bilinear2x_backward(
+                g.data_ptr(), gin.data_ptr(), B * C, H, W, torch.cuda.current_stream(g.device).cuda_stream),
+                'tai_upsample_bilinear2x_backward')
+        return gin
 
 
 def upsample2x(x):
