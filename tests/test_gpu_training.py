@@ -26,7 +26,7 @@ GRAD_KEYS = ('generator.motion_enc.dyn_conv1.0.weight',      # first convolution
              'kernelnet.moduleConv.0.0.weight', 'kernelnet.moduleUpsample.3.1.weight',
              'kernelnet.moduleVertical1.7.weight', 'kernelnet.moduleHorizontal2.7.bias')
 LOSS_RTOL = 2e-4          # loss terms, relative
-GRAD_RTOL = 5e-3          # max |g_gpu - g_oracle| <= GRAD_RTOL * max |g_oracle| per parameter (measured: <= 1.7e-3, profiles/r02_training_parity.txt)
+GRAD_RTOL = 5e-3          # max |g_gpu - g_oracle| <= GRAD_RTOL * max |g_oracle| per parameter (measured: <= 3.3e-3, profiles/r02_training_parity.txt)
 
 
 @pytest.fixture(autouse=True)
