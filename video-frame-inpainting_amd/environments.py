@@ -134,6 +134,7 @@ class BaseTrainingEnvironment(BaseVideoFillInEnvironment):
     """environments.py:122-259."""
 
     STEP_GRAPH_WARMUP = 2      # eager updates per (K, T, F, batch shape) before the update is captured
+    MAX_STEP_GRAPHS = 2        # a captured update keeps its activations (tens of GB at cfg3): further shapes (--sample_KTF) stay eager
 
     def __init__(self, fill_in_model, checkpoints_dir, name, lr, beta1, max_K, max_T, max_F, padding_size, device=None,
                  graph_step=False):
@@ -191,7 +192,9 @@ class BaseTrainingEnvironment(BaseVideoFillInEnvironment):
             return
         key = (self.K, self.T, self.F, tuple(preceding_frames.shape), tuple(following_frames.shape), tuple(gt_middle_frames.shape))
         state = self._step_graphs.setdefault(key, {'eager': 0})
-        if state['eager'] < self.STEP_GRAPH_WARMUP:       # MIOpen's algorithm search, lazy allocations, Adam's state
+        captured = sum(1 for v in self._step_graphs.values() if 'graph' in v)
+        if state['eager'] < self.STEP_GRAPH_WARMUP or ('graph' not in state and captured >= self.MAX_STEP_GRAPHS):
+            # MIOpen's algorithm search, lazy allocations, Adam's state -- or no room for another captured update
             state['eager'] += 1
             self.set_train_inputs(preceding_frames, following_frames, gt_middle_frames)
             self.forward_train()
