@@ -108,6 +108,16 @@ int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float*
  * 45-47).  W % 4 == 0. */
 int tai_conv_shift_stack(const float* x, float* out, int N, int C, int H, int W, int k, void* hip_stream);
 
+/* Element-wise tail of a discriminator layer evaluated on all sliding windows at once (nw window groups of B images stacked
+ * along the batch; window t's weight is w0 * inv_scale[t], src/discriminators/SNDiscriminator.py:60-68, 140-159):
+ *   forward, in place:  y = leaky_relu(y * inv_scale[window] + bias[channel], slope)          y [nw * B, C, HW], HW % 4 == 0
+ *   backward:  grad_z = grad_y * (y > 0 ? 1 : slope)  (the pre-activation's gradient: weight / bias gradients take it),
+ *              grad_scaled = grad_z * inv_scale[window]  (what flows into the input gradient through w0). */
+int tai_window_scale_bias_lrelu(float* y, const float* bias, const float* inv_scale, int nw, int B, int C, int HW, float slope,
+                                void* hip_stream);
+int tai_window_scale_lrelu_backward(const float* grad_y, const float* y, const float* inv_scale, float* grad_z, float* grad_scaled,
+                                    int nw, int B, int C, int HW, float slope, void* hip_stream);
+
 /* Weight and bias gradients of the thin layers (tai_conv_cin1_forward / tai_conv_cout1_3x3_forward under loss.backward()):
  *   dw[cb][a][b] = sum over n, y, x of big[n, cb, y, x] * thin[n, 0, y + a - k/2, x + b - k/2]  (zero padding),  dbias[cb] = sum of big[n, cb]
  * big [N, Cb, H, W], thin [N, 1, H, W] fp32 contiguous, W % 4 == 0, k in {3, 5}; dw [Cb, k, k] or dbias [Cb] may be NULL;

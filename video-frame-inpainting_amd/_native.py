@@ -115,6 +115,10 @@ def lib():
     L.tai_conv3x3_wino_wrw_window.restype = I
     L.tai_conv3x3_wino_wrw_set_paired.argtypes = [I]
     L.tai_conv3x3_wino_wrw_set_paired.restype = I
+    L.tai_window_scale_bias_lrelu.argtypes = [P, P, P, I, I, I, I, ctypes.c_float, V]
+    L.tai_window_scale_bias_lrelu.restype = I
+    L.tai_window_scale_lrelu_backward.argtypes = [P, P, P, P, P, I, I, I, I, ctypes.c_float, V]
+    L.tai_window_scale_lrelu_backward.restype = I
     L.tai_thin_conv_wrw.argtypes = [P, P, P, P, P, I, I, I, I, I, V]
     L.tai_thin_conv_wrw.restype = I
     L.tai_act_maxpool2x2_forward.argtypes = [P, P, P, ctypes.c_longlong, I, I, I, V]

@@ -412,6 +412,30 @@ int tai_sn_power_iteration(float* weight, float* u, float* scratch, float* sigma
     return check_launch("sn_power_iteration");
 }
 
+int tai_window_scale_bias_lrelu(float* y, const float* bias, const float* inv_scale, int nw, int B, int C, int HW, float slope,
+                                void* hip_stream) {
+    g_err[0] = 0;
+    if (!y || !bias || !inv_scale) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (nw <= 0 || B <= 0 || C <= 0 || HW <= 0 || HW % 4 != 0) return fail(TAI_SEPCONV_EINVAL, "%s", "window_scale_bias_lrelu: needs HW % 4 == 0");
+    const long long n4 = (long long)nw * B * C * (HW / 4);
+    const int blocks = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(snorm::window_scale_bias_lrelu, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), y, bias,
+                       inv_scale, n4, C * (HW / 4), HW / 4, C, B, slope);
+    return check_launch("window_scale_bias_lrelu");
+}
+
+int tai_window_scale_lrelu_backward(const float* grad_y, const float* y, const float* inv_scale, float* grad_z, float* grad_scaled,
+                                    int nw, int B, int C, int HW, float slope, void* hip_stream) {
+    g_err[0] = 0;
+    if (!grad_y || !y || !inv_scale || !grad_z || !grad_scaled) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (nw <= 0 || B <= 0 || C <= 0 || HW <= 0 || HW % 4 != 0) return fail(TAI_SEPCONV_EINVAL, "%s", "window_scale_lrelu_backward: needs HW % 4 == 0");
+    const long long n4 = (long long)nw * B * C * (HW / 4);
+    const int blocks = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(snorm::window_scale_lrelu_backward, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), grad_y, y,
+                       inv_scale, grad_z, grad_scaled, n4, C * (HW / 4), B, slope);
+    return check_launch("window_scale_lrelu_backward");
+}
+
 int tai_thin_conv_wrw(const float* big, const float* thin, float* dw, float* dbias, float* workspace, int N, int Cb, int H, int W,
                       int k, void* hip_stream) {
     g_err[0] = 0;

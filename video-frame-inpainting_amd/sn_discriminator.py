@@ -136,6 +136,46 @@ class _WindowScaledConv(torch.autograd.Function):
         return gx, gw, None, gb, None, None, None, None
 
 
+class _WindowScaledConvLReLU(torch.autograd.Function):
+    """_WindowScaledConv followed by LeakyReLU(slope), the element-wise tail (per-window factor, bias, activation) in one
+    pass forwards and one backwards (tai_window_scale_bias_lrelu / _backward) instead of three and two."""
+
+    @staticmethod
+    def forward(ctx, x, weight, w0, bias, inv_scale, nw, stride, padding, slope):
+        from . import _native
+        y = F.conv2d(x, w0, None, stride, padding).contiguous()
+        N, Co, H, W = y.shape
+        with torch.cuda.device(y.device):
+            _native.check(_native.lib().tai_window_scale_bias_lrelu(
+                y.data_ptr(), bias.data_ptr(), inv_scale.data_ptr(), nw, N // nw, Co, H * W, float(slope),
+                torch.cuda.current_stream(y.device).cuda_stream), 'tai_window_scale_bias_lrelu')
+        ctx.save_for_backward(x, w0, inv_scale, y)
+        ctx.cfg = (nw, stride, padding, float(slope))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _native
+        x, w0, inv_scale, y = ctx.saved_tensors
+        nw, stride, padding, slope = ctx.cfg
+        g = g.contiguous()
+        N, Co, H, W = g.shape
+        gz, gs = torch.empty_like(g), torch.empty_like(g)
+        with torch.cuda.device(g.device):
+            _native.check(_native.lib().tai_window_scale_lrelu_backward(
+                g.data_ptr(), y.data_ptr(), inv_scale.data_ptr(), gz.data_ptr(), gs.data_ptr(), nw, N // nw, Co, H * W, slope,
+                torch.cuda.current_stream(g.device).cuda_stream), 'tai_window_scale_lrelu_backward')
+        gx = gw = gb = None
+        conv_bwd = torch.ops.aten.convolution_backward
+        if ctx.needs_input_grad[1]:
+            gw = conv_bwd(gz, x, w0, [Co], list(stride), list(padding), [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        if ctx.needs_input_grad[0]:
+            gx = conv_bwd(gs, x, w0, [Co], list(stride), list(padding), [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[3]:
+            gb = gz.sum((0, 2, 3))
+        return gx, gw, None, gb, None, None, None, None, None
+
+
 class _WindowScaledLinear(torch.autograd.Function):
     """The same for the one-logit linear layer: y[t] = feats[t] @ w0^T * inv_scale[t] + bias."""
 
@@ -229,12 +269,24 @@ class SNDiscriminator(nn.Module):
         B, T, C, H, W = input.shape
         ws = self.window_size
         x = torch.stack([input[:, t0:t0 + ws].reshape(B, ws * C, H, W) for t0 in range(nw)], dim=0).view(nw * B, ws * C, H, W)
-        for layer in self.conv_layers:
+        layers = list(self.conv_layers)
+        i = 0
+        while i < len(layers):
+            layer = layers[i]
             if isinstance(layer, SNConv2d):
                 w0, inv_scale = layer.renormalise_sequence_(nw)
+                nxt = layers[i + 1] if i + 1 < len(layers) else None
+                oh = (x.shape[2] + 2 * layer.padding[0] - layer.kernel_size[0]) // layer.stride[0] + 1
+                ow = (x.shape[3] + 2 * layer.padding[1] - layer.kernel_size[1]) // layer.stride[1] + 1
+                if isinstance(nxt, nn.LeakyReLU) and layer.bias is not None and (oh * ow) % 4 == 0:
+                    x = _WindowScaledConvLReLU.apply(x, layer.weight, w0, layer.bias, inv_scale, nw, layer.stride, layer.padding,
+                                                     nxt.negative_slope)
+                    i += 2
+                    continue
                 x = _WindowScaledConv.apply(x, layer.weight, w0, layer.bias, inv_scale, nw, layer.stride, layer.padding)
             else:
                 x = layer(x)
+            i += 1
         w0, inv_scale = self.linear_layer.renormalise_sequence_(nw)
         logits = _WindowScaledLinear.apply(x.reshape(nw * B, self.num_sn_linear_in_feats), self.linear_layer.weight, w0,
                                            self.linear_layer.bias, inv_scale, nw)
