@@ -78,6 +78,11 @@ int tai_unpool2x_add(const float* x, const float* res, float* out, long long pla
  *   new_c = c * sigmoid(f + forget_bias) + sigmoid(i) * tanh(j);   new_h = tanh(new_c) * sigmoid(o). */
 int tai_convlstm_gates_forward(const float* gates, const float* c, float* new_c, float* new_h, int N, int F, int HW,
                                float forget_bias, void* hip_stream);
+/* Its gradient: from dL/dnew_c and dL/dnew_h (either may be NULL: no gradient on that path) to grad_gates [N, 4F, HW] and
+ * grad_c [N, F, HW]; gates, c and new_c as in the forward call. */
+int tai_convlstm_gates_backward(const float* gates, const float* c, const float* new_c, const float* grad_new_c,
+                                const float* grad_new_h, float* grad_gates, float* grad_c, int N, int F, int HW, float forget_bias,
+                                void* hip_stream);
 
 /* Direct "same"-padded stride-1 convolutions for the generator's thin layers, bias and activation fused (act: 0 none,
  * 1 ReLU, 2 tanh), fp32 NCHW contiguous, W % 4 == 0:

@@ -323,3 +323,26 @@ def test_train_driver_on_a_video_list(tmp_path, monkeypatch):
                 '--checkpoints_dir', str(tmp_path / 'ckpt'), '--batch_size', '2', '--max_iter', '2', '--print_freq', '1',
                 '--df_dim', '8', '--train_video_list_path', str(tmp_path / 'train.txt'), '--num_threads', '0'])
     assert (tmp_path / 'ckpt' / 'lst' / 'model_latest.ckpt').exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('paths', ['both', 'h_only', 'c_only'])
+def test_convlstm_gates_training_form_matches_aten(paths):
+    """_LstmGates (tai_convlstm_gates_forward / _backward) against the reference's expression (mcnet.py:287-293) under fp64
+    autograd: values, and the gradients of the gates tensor and of c from either or both outputs."""
+    from video_frame_inpainting_amd.mcnet import _LstmGates
+    g = torch.Generator().manual_seed(12)
+    N, F_, H, W = 3, 16, 6, 10
+    gates = torch.randn(N, 4 * F_, H, W, generator=g).cuda().requires_grad_(True)
+    c = torch.randn(N, F_, H, W, generator=g).cuda().requires_grad_(True)
+    gc, gh = torch.randn(N, F_, H, W, generator=g).cuda(), torch.randn(N, F_, H, W, generator=g).cuda()
+    new_c, new_h = _LstmGates.apply(gates, c, 1.0)
+    gd, cd = gates.detach().double().requires_grad_(True), c.detach().double().requires_grad_(True)
+    i, j, f, o = torch.chunk(gd, 4, dim=1)
+    rc = cd * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+    rh = torch.tanh(rc) * torch.sigmoid(o)
+    assert float((new_c.double() - rc).abs().max()) <= 2e-6 and float((new_h.double() - rh).abs().max()) <= 2e-6
+    loss = lambda a, b: ((a * gc.to(a.dtype)).sum() if paths != 'h_only' else 0) + ((b * gh.to(b.dtype)).sum() if paths != 'c_only' else 0)
+    dg, dc = torch.autograd.grad(loss(new_c, new_h), (gates, c))
+    rg, rcg = torch.autograd.grad(loss(rc, rh), (gd, cd))
+    assert float((dg.double() - rg).abs().max()) <= 5e-6 and float((dc.double() - rcg).abs().max()) <= 5e-6

@@ -107,6 +107,8 @@ def lib():
     L.tai_unpool2x_add.restype = I
     L.tai_convlstm_gates_forward.argtypes = [P, P, P, P, I, I, I, ctypes.c_float, V]
     L.tai_convlstm_gates_forward.restype = I
+    L.tai_convlstm_gates_backward.argtypes = [P, P, P, P, P, P, P, I, I, I, ctypes.c_float, V]
+    L.tai_convlstm_gates_backward.restype = I
     L.tai_conv3x3_wino_wrw_workspace_floats.argtypes = [I] * 5
     L.tai_conv3x3_wino_wrw_workspace_floats.restype = ctypes.c_longlong
     L.tai_conv3x3_wino_wrw.argtypes = [P, P, P, P, P, I, I, I, I, I, V]

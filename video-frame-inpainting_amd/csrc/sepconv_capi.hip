@@ -474,6 +474,19 @@ int tai_act_maxpool2x2_backward(const float* grad_y, const float* grad_ypool, co
     return check_launch("act_maxpool2x2_backward");
 }
 
+int tai_convlstm_gates_backward(const float* gates, const float* c, const float* new_c, const float* grad_new_c,
+                                const float* grad_new_h, float* grad_gates, float* grad_c, int N, int F, int HW, float forget_bias,
+                                void* hip_stream) {
+    g_err[0] = 0;
+    if (!gates || !c || !new_c || !grad_gates || !grad_c || (!grad_new_c && !grad_new_h)) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (N <= 0 || F <= 0 || HW <= 0 || HW % 4 != 0) return fail(TAI_SEPCONV_EINVAL, "%s", "convlstm_gates: needs HW % 4 == 0");
+    const long long work = (long long)N * F * (HW / 4);
+    const int blocks = (int)((work + 255) / 256 < 16384 ? (work + 255) / 256 : 16384);
+    hipLaunchKernelGGL(bact::convlstm_gates_backward, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), gates, c,
+                       new_c, grad_new_c, grad_new_h, grad_gates, grad_c, N, F, HW / 4, forget_bias);
+    return check_launch("convlstm_gates_backward");
+}
+
 int tai_conv_shift_stack(const float* x, float* out, int N, int C, int H, int W, int k, void* hip_stream) {
     g_err[0] = 0;
     if (!x || !out) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");

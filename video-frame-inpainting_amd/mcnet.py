@@ -181,6 +181,41 @@ class DecCnn(nn.Module):
     fixed_unpooling = staticmethod(lambda x: unpool2x_add(x, x.new_zeros(x.shape[0], x.shape[1], 2 * x.shape[2], 2 * x.shape[3])))
 
 
+class _LstmGates(torch.autograd.Function):
+    """(new_c, new_h) from the gates tensor and c under autograd: tai_convlstm_gates_forward / _backward, one kernel each."""
+
+    @staticmethod
+    def forward(ctx, gates, c, forget_bias):
+        from . import _native
+        gates, c = gates.contiguous(), c.contiguous()
+        N, F4, H, W = gates.shape
+        new_c, new_h = torch.empty_like(c), torch.empty_like(c)
+        with torch.cuda.device(gates.device):
+            _native.check(_native.lib().tai_convlstm_gates_forward(
+                gates.data_ptr(), c.data_ptr(), new_c.data_ptr(), new_h.data_ptr(), N, F4 // 4, H * W, float(forget_bias),
+                torch.cuda.current_stream(gates.device).cuda_stream), 'tai_convlstm_gates_forward')
+        ctx.forget_bias = float(forget_bias)
+        ctx.save_for_backward(gates, c, new_c)
+        return new_c, new_h
+
+    @staticmethod
+    def backward(ctx, g_c, g_h):
+        from . import _native
+        gates, c, new_c = ctx.saved_tensors
+        N, F4, H, W = gates.shape
+        if g_c is None and g_h is None:
+            return None, None, None
+        g_c = g_c.contiguous() if g_c is not None else None
+        g_h = g_h.contiguous() if g_h is not None else None
+        d_gates, d_c = torch.empty_like(gates), torch.empty_like(c)
+        with torch.cuda.device(gates.device):
+            _native.check(_native.lib().tai_convlstm_gates_backward(
+                gates.data_ptr(), c.data_ptr(), new_c.data_ptr(), g_c.data_ptr() if g_c is not None else None,
+                g_h.data_ptr() if g_h is not None else None, d_gates.data_ptr(), d_c.data_ptr(), N, F4 // 4, H * W, ctx.forget_bias,
+                torch.cuda.current_stream(gates.device).cuda_stream), 'tai_convlstm_gates_backward')
+        return d_gates, d_c, None
+
+
 class ConvLstmCell(nn.Module):
     """mcnet.py:259-294.  state = cat(c, h); gates (i, j, f, o) = chunks of conv(cat(input, h));
     c' = c * sigmoid(f + forget_bias) + sigmoid(i) * tanh(j);  h' = tanh(c') * sigmoid(o)."""
@@ -221,6 +256,8 @@ class ConvLstmCell(nn.Module):
                 _native.check(_native.lib().tai_convlstm_gates_forward(
                     gates.data_ptr(), c.data_ptr(), new_c.data_ptr(), new_h.data_ptr(), N, F4 // 4, H * W,
                     float(self.forget_bias), torch.cuda.current_stream(gates.device).cuda_stream), 'tai_convlstm_gates_forward')
+        elif gates.is_cuda and gates.dtype == torch.float32 and (H * W) % 4 == 0 and c.dtype == torch.float32:
+            new_c, new_h = _LstmGates.apply(gates, c, self.forget_bias)           # training: the same kernel, and its gradient
         else:
             i, j, f, o = torch.chunk(gates, 4, dim=1)
             new_c = c * torch.sigmoid(f + self.forget_bias) + torch.sigmoid(i) * torch.tanh(j)
