@@ -103,6 +103,10 @@ int tai_conv_cin1_forward_maxpool_window(const float* x, const float* weight, co
                                          void* hip_stream);
 int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float* bias, float* y, int N, int Ci, int H,
                                int W, int act, void* hip_stream);
+/* ... 5 x 5, padding 2, no activation, bias may be NULL: x [N,Ci,H,W], weight [1,Ci,5,5] -> y [N,1,H,W]; the input gradient of
+ * tai_conv_cin1_forward (k = 5) when the input frame is itself generated (weight = the layer's filter flipped). */
+int tai_conv_cout1_5x5_forward(const float* x, const float* weight, const float* bias, float* y, int N, int Ci, int H, int W,
+                               void* hip_stream);
 
 /* k x k (k = 5, 7) "same" convolution as a 3x3 convolution: out [N, S*S*C, H+2, W+4] (S = 2 for k = 5, 3 for k = 7)
  * receives the S*S shifted copies of x [N, C, H, W], each with its own halo -- out[n][(a*S+b)*C+c][u][v] =

@@ -160,19 +160,19 @@ def test_one_input_channel_layer_training_form(k, act):
     from video_frame_inpainting_amd import conv_ops
     g = torch.Generator().manual_seed(k)
     N, Co, H, W = 6, 64, 24, 40
-    x = torch.randn(N, 1, H, W, generator=g).cuda()
+    x = torch.randn(N, 1, H, W, generator=g).cuda().requires_grad_(True)     # (a generated frame difference needs its gradient)
     w = (torch.randn(Co, 1, k, k, generator=g) * 0.2).cuda().requires_grad_(True)
     b = torch.randn(Co, generator=g).cuda().requires_grad_(True)
     go = torch.randn(N, Co, H, W, generator=g).cuda()
     y = conv_ops.conv_bias_act(x, w, b, k // 2, act)
     assert type(y.grad_fn).__name__ == '_ThinInConvBackward'
-    gw, gb = torch.autograd.grad(y, (w, b), go)
-    wd, bd = w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
-    yd = F.conv2d(x.double(), wd, bd, padding=k // 2)
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), go)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yd = F.conv2d(xd, wd, bd, padding=k // 2)
     yd = yd * (y.detach() > 0) if act == 'relu' else yd
-    rw, rb = torch.autograd.grad(yd, (wd, bd), go.double())
+    rx, rw, rb = torch.autograd.grad(yd, (xd, wd, bd), go.double())
     assert float((y.double() - yd).abs().max()) <= 1e-5
-    for got, ref in ((gw, rw), (gb, rb)):
+    for got, ref in ((gx, rx), (gw, rw), (gb, rb)):
         assert float((got.double() - ref).abs().max()) <= 1e-4 * (1 + float(ref.abs().max()))
     assert torch.equal(torch.autograd.grad(conv_ops.conv_bias_act(x, w, b, k // 2, act), w, go)[0], gw)      # reproducible
 

@@ -133,6 +133,8 @@ def lib():
     L.tai_conv_shift_stack.restype = I
     L.tai_conv_cout1_3x3_forward.argtypes = [P, P, P, P, I, I, I, I, I, V]
     L.tai_conv_cout1_3x3_forward.restype = I
+    L.tai_conv_cout1_5x5_forward.argtypes = [P, P, P, P, I, I, I, I, V]
+    L.tai_conv_cout1_5x5_forward.restype = I
     L.tai_bias_act_inplace.argtypes = [P, P, I, I, I, I, V]
     L.tai_bias_act_inplace.restype = I
     L.tai_sepconv_set_forward_variant.argtypes = [I]

@@ -452,8 +452,19 @@ class _ThinInConv(torch.autograd.Function):
         Co, k = weight.shape[0], weight.shape[2]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(g, x, weight, [Co], [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
-                                                     [True, False, False])[0]
+            # (the frame difference of an autoregressive step is itself generated)
+            N, _, H, W = x.shape
+            L = _native.lib()
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            wf = weight.detach().flip(2, 3).transpose(0, 1).contiguous()                 # [1, Co, k, k]: the filter flipped
+            gx = torch.empty_like(x)
+            with torch.cuda.device(x.device):
+                if k == 5:
+                    _native.check(L.tai_conv_cout1_5x5_forward(g.data_ptr(), wf.data_ptr(), None, gx.data_ptr(), N, Co, H, W, stream),
+                                  'tai_conv_cout1_5x5_forward')
+                else:
+                    _native.check(L.tai_conv_cout1_3x3_forward(g.data_ptr(), wf.data_ptr(), _zero_bias(1, x.device).data_ptr(),
+                                                               gx.data_ptr(), N, Co, H, W, 0, stream), 'tai_conv_cout1_3x3_forward')
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw, gb = thin_weight_grad(g, x, k)
             gw = dw.view_as(weight)

@@ -514,6 +514,18 @@ int tai_conv_cout1_3x3_forward(const float* x, const float* weight, const float*
     return check_launch("conv_cout1_3x3");
 }
 
+int tai_conv_cout1_5x5_forward(const float* x, const float* weight, const float* bias, float* y, int N, int Ci, int H, int W,
+                               void* hip_stream) {
+    g_err[0] = 0;
+    if (!x || !weight || !y) return fail(TAI_SEPCONV_EINVAL, "%s", "null pointer");
+    if (N <= 0 || Ci <= 0 || H <= 0 || W <= 0 || W % 4 != 0) return fail(TAI_SEPCONV_EINVAL, "%s", "conv_cout1_5x5: needs W % 4 == 0");
+    const long long work = (long long)N * H * (W / 4);
+    const int blocks = (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192);
+    hipLaunchKernelGGL(thin::conv_cout1_5x5, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), x, weight, bias, y, N, Ci,
+                       H, W);
+    return check_launch("conv_cout1_5x5");
+}
+
 long long tai_conv3x3_wino_weight_floats(int K, int C) {
     if (K <= 0 || C <= 0) return 0;
     const long long Kpad = (K + wino::TM - 1) / wino::TM * wino::TM, Cpad = (C + wino::KC - 1) / wino::KC * wino::KC;
