@@ -198,3 +198,26 @@ def test_one_output_channel_layer_training_form(transposed):
     assert float((y.double() - yd).abs().max()) <= 1e-5
     for got, ref in ((gx, rx), (gw, rw), (gb, rb)):
         assert float((got.double() - ref).abs().max()) <= 1e-4 * (1 + float(ref.abs().max()))
+
+
+def test_training_entry_points_reject_bad_arguments():
+    """Every training entry of the C ABI validates before it launches: null pointers, shapes it does not take."""
+    from video_frame_inpainting_amd import _native
+    L = _native.lib()
+    x = torch.zeros(1, 8, 8, 16, device='cuda')
+    p = x.data_ptr()
+    s = torch.cuda.current_stream().cuda_stream
+    assert L.tai_thin_conv_wrw(p, p, p, p, p, 1, 8, 8, 16, 4, s) != 0                     # k not in {3, 5}
+    assert L.tai_thin_conv_wrw(p, p, None, None, p, 1, 8, 8, 16, 3, s) != 0               # neither output wanted
+    assert L.tai_thin_conv_wrw(p, p, p, p, p, 1, 8, 8, 18, 3, s) != 0                     # W % 4
+    assert L.tai_act_maxpool2x2_forward(p, p, p, 8, 7, 16, 1, s) != 0                     # odd H
+    assert L.tai_act_maxpool2x2_backward(None, None, p, None, 8, 8, 16, 1, s) != 0        # no output
+    assert L.tai_window_scale_bias_lrelu(p, p, p, 1, 1, 8, 6, 0.2, s) != 0                # HW % 4
+    assert L.tai_window_scale_lrelu_backward(p, p, p, None, p, 1, 1, 8, 128, 0.2, s) != 0
+    assert L.tai_convlstm_gates_backward(p, p, p, None, None, p, p, 1, 2, 128, 1.0, s) != 0   # no incoming gradient
+    assert L.tai_sn_power_iteration(p, p, p, None, 8, 16, 0, s) != 0                      # Ip < 1
+    assert L.tai_upsample_bilinear2x_backward(None, p, 1, 4, 4, s) != 0
+    assert L.tai_conv_cout1_5x5_forward(p, p, None, p, 1, 8, 8, 18, s) != 0               # W % 4
+    assert L.tai_conv3x3_wino_wrw_window(p, p, p, None, p, 1, 8, 8, 8, 16, 8, 16, 1, 2, s) != 0   # window outside the plane
+    assert b'window' in L.tai_sepconv_last_error() or len(L.tai_sepconv_last_error()) > 0
+    torch.cuda.synchronize()
