@@ -203,7 +203,8 @@ def test_graphed_update_matches_the_eager_update(tmp_path):
         for k, v in getattr(envs['graph'], part).state_dict().items():
             # Adam normalises every gradient element by its own running magnitude: where a gradient is at rounding level
             # (MIOpen's atomics reorder sums from run to run) the update's direction is noise, so single elements may
-            # differ by up to lr x updates = 4e-3 each way (seen: one run in eight beyond 4.5e-3); anything systematic (a stale weight, a skipped update) is far larger
+            # differ by up to lr x updates = 4e-3 each way (eight runs: max 1.5e-5 .. 3.4e-3, mean over a tensor <= 1.5e-5, loss terms <= 3.6e-5
+            # relative); anything systematic (a stale weight, a skipped update) is far larger
             diff = (v - ref[k]).abs()
             assert float(diff.max()) <= 8e-3, (part, k, float(diff.max()))           # 2 x lr x updates: Adam's reach
             assert float(diff.mean()) <= 2e-4, (part, k, float(diff.mean()))         # a missed update moves every element by ~lr = 1e-3
