@@ -255,9 +255,110 @@ def ablations():
     print('ablations.npz: %d arrays' % len(out))
 
 
+def sn_disc():
+    """The reference's spectral-norm discriminator (src/discriminators/SNDiscriminator.py) run on CPU -> sn_disc.npz.
+
+    ``max_singular_value`` / ``_l2normalize`` (:10-33) and ``SNLinear`` (:71-92) run as they are.  ``SNConv2d.__init__``
+    (:60-61) passes torch 0.3.1's ten positional arguments to ``_ConvNd.__init__``; torch 2.x added a required
+    ``padding_mode`` after them, so that ONE base-class constructor is wrapped here to default it to 'zeros' while the
+    reference's modules are constructed (restored afterwards).  ``SNDiscriminator.forward`` (:140-159) needs ``xrange``
+    (install_shims).  Every forward of every layer overwrites ``weight.data`` and keeps ``u``, so the fixture records
+    weights, u vectors and logits over CONSECUTIVE calls.  Gradients are recorded only for a single-window, single-call
+    evaluation: there no later renormalisation touches a weight between its use and the backward pass, so torch 2.x's
+    autograd (which reads a leaf parameter's data at backward time) and torch 0.3.1's (which kept the tensor of the
+    moment) give the same numbers."""
+    from torch.nn.modules import conv as tconv
+    orig_init = tconv._ConvNd.__init__
+
+    def init_with_default_padding_mode(self, *args, **kw):
+        if len(args) == 10 and 'padding_mode' not in kw:
+            args = args + ('zeros',)
+        return orig_init(self, *args, **kw)
+
+    tconv._ConvNd.__init__ = init_with_default_padding_mode
+    try:
+        from src.discriminators import SNDiscriminator as ref
+        g = torch.Generator().manual_seed(777)
+        out = {}
+
+        def put(name, **arrs):
+            for k, v in arrs.items():
+                out['%s/%s' % (name, k)] = np.ascontiguousarray(v.detach().numpy() if isinstance(v, torch.Tensor) else v)
+
+        # ---- max_singular_value with a given u, Ip = 1 and 3 (:10-25)
+        W = rnd(g, 8, 48) * 0.3
+        u = rnd(g, 1, 8)
+        for Ip in (1, 3):
+            sigma, u_out = ref.max_singular_value(torch.nn.Parameter(W.clone()), u.clone(), Ip=Ip)
+            put('msv_ip%d' % Ip, W=W, u=u, sigma=sigma, u_out=u_out)
+        v = rnd(g, 1, 13)
+        put('l2normalize', v=v, out=ref._l2normalize(v))
+
+        # ---- SNLinear over three consecutive forwards (:84-92)
+        lin = ref.SNLinear(48, 1, Ip=1)
+        seeded_init(lin, 51)
+        lin.u = rnd(g, 1, 1)
+        x = rnd(g, 3, 48)
+        put('sn_linear', W0=lin.weight.data.clone(), b=lin.bias.data.clone(), u0=lin.u.clone(), x=x)
+        for call in range(3):
+            y = lin(x)
+            put('sn_linear', **{'out%d' % call: y, 'W%d' % (call + 1): lin.weight.data.clone(), 'u%d' % (call + 1): lin.u.clone()})
+
+        # ---- SNConv2d 4x4 stride 2 pad 1 over three consecutive forwards (:60-68)
+        cv = ref.SNConv2d(3, 8, 4, stride=2, padding=1, Ip=3)
+        seeded_init(cv, 52)
+        cv.u = rnd(g, 1, 8)
+        x = rnd(g, 2, 3, 16, 16)
+        put('sn_conv', W0=cv.weight.data.clone(), b=cv.bias.data.clone(), u0=cv.u.clone(), x=x)
+        for call in range(3):
+            y = cv(x)
+            put('sn_conv', **{'out%d' % call: y, 'W%d' % (call + 1): cv.weight.data.clone(), 'u%d' % (call + 1): cv.u.clone()})
+
+        # ---- SNDiscriminator.forward (:95-159): 5 windows of 3 frames, two consecutive calls on different clips
+        for tag, c_dim in (('disc_gray', 1), ('disc_color', 3)):
+            D = ref.SNDiscriminator((32, 32), c_dim, 3, 4, 3)
+            seeded_init(D, 53 + c_dim)
+            for name, m in D.named_modules():
+                if hasattr(m, 'Ip'):
+                    m.u = rnd(g, 1, m.weight.size(0))
+                    put(tag, **{'u0/' + name: m.u.clone()})
+            put(tag, **{'w0/' + k: v for k, v in sd_np(D).items()})
+            for call in range(2):
+                frames = torch.tanh(rnd(g, 2, 7, c_dim, 32, 32))
+                logits = D(frames)
+                put(tag, **{'frames%d' % call: frames, 'logits%d' % call: logits})
+                put(tag, **{'w%d/%s' % (call + 1, k): v for k, v in sd_np(D).items()})
+                for name, m in D.named_modules():
+                    if hasattr(m, 'Ip'):
+                        put(tag, **{'u%d/%s' % (call + 1, name): m.u.clone()})
+
+        # ---- one window, one call, BCE-with-logits against ones, gradients of every parameter
+        D = ref.SNDiscriminator((32, 32), 1, 3, 4, 3)
+        seeded_init(D, 60)
+        for name, m in D.named_modules():
+            if hasattr(m, 'Ip'):
+                m.u = rnd(g, 1, m.weight.size(0))
+                put('disc_grad', **{'u0/' + name: m.u.clone()})
+        put('disc_grad', **{'w0/' + k: v for k, v in sd_np(D).items()})
+        frames = torch.tanh(rnd(g, 2, 3, 1, 32, 32)).requires_grad_(True)
+        logits = D(frames)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
+        loss.backward()
+        put('disc_grad', frames=frames, logits=logits, loss=loss.reshape(1), grad_frames=frames.grad)
+        put('disc_grad', **{'grad/' + k: p.grad for k, p in D.named_parameters()})
+        put('disc_grad', **{'w1/' + k: v for k, v in sd_np(D).items()})
+        np.savez_compressed(os.path.join(HERE, 'sn_disc.npz'), **out)
+        print('sn_disc.npz: %d arrays' % len(out))
+    finally:
+        tconv._ConvNd.__init__ = orig_init
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'ablations':
         install_shims()
         ablations()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'sn_disc':
+        install_shims()
+        sn_disc()
     else:
         main()

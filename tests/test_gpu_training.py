@@ -219,3 +219,83 @@ def test_graphed_update_matches_the_eager_update(tmp_path):
     assert float((outs[0] - outs[1]).abs().max()) <= 5e-3
     # ... and not the weights of the update before (what the captured Winograd filters were computed from)
     assert torch.isfinite(outs[1]).all()
+
+
+# ---- reference-run pins (tests/golden/sn_disc.npz: the reference's own SNDiscriminator.py run on CPU by make_golden.py) ----
+def _sn_group(z, prefix):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('Ip', [1, 3])
+def test_sn_power_iteration_kernel_matches_reference_run(golden_dir, Ip):
+    """tai_sn_power_iteration against max_singular_value of the reference (SNDiscriminator.py:10-25) with a given u."""
+    import os
+    from video_frame_inpainting_amd.sn_discriminator import SNLinear
+    z = np.load(os.path.join(golden_dir, 'sn_disc.npz'))
+    W, u = torch.from_numpy(z['msv_ip%d/W' % Ip]), torch.from_numpy(z['msv_ip%d/u' % Ip])
+    layer = SNLinear(W.shape[1], W.shape[0], Ip=Ip).to(DEV)
+    with torch.no_grad():
+        layer.weight.copy_(W)
+    layer.u = u.to(DEV)
+    layer._renormalise_()
+    sigma = z['msv_ip%d/sigma' % Ip].reshape(-1)[0]
+    np.testing.assert_allclose(float(layer.last_sigma), float(sigma), rtol=2e-6)
+    np.testing.assert_allclose(layer.u.cpu().numpy(), z['msv_ip%d/u_out' % Ip], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(layer.weight.detach().cpu().numpy(), (W / float(sigma)).numpy(), rtol=5e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag, c_dim', [('disc_gray', 1), ('disc_color', 3)])
+def test_gpu_discriminator_matches_reference_run_over_two_calls(golden_dir, tag, c_dim):
+    """The product's all-windows-in-one-pass discriminator (renormalisations up front, one factor per window) against
+    the reference's window-by-window SNDiscriminator.forward (:140-159) over two consecutive calls: logits, the
+    in-place renormalised weights and the persistent u vectors."""
+    import os
+    from video_frame_inpainting_amd.sn_discriminator import SNDiscriminator
+    z = np.load(os.path.join(golden_dir, 'sn_disc.npz'))
+    w0, u0 = _sn_group(z, tag + '/w0/'), _sn_group(z, tag + '/u0/')
+    disc = SNDiscriminator((32, 32), c_dim, 3, 4, 3)
+    disc.load_state_dict(w0)
+    disc.to(DEV)
+    mods = dict(disc.named_modules())
+    for name, u in u0.items():
+        mods[name].u = u.to(DEV)
+    for call in range(2):
+        frames = torch.from_numpy(z['%s/frames%d' % (tag, call)]).to(DEV)
+        want = z['%s/logits%d' % (tag, call)]
+        with torch.no_grad():
+            got = disc(frames)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-5 * float(np.abs(want).max()))
+        for k, v in _sn_group(z, '%s/w%d/' % (tag, call + 1)).items():
+            np.testing.assert_allclose(disc.state_dict()[k].cpu().numpy(), v.numpy(), rtol=2e-5, atol=1e-7, err_msg=k)
+        for k, v in _sn_group(z, '%s/u%d/' % (tag, call + 1)).items():
+            np.testing.assert_allclose(mods[k].u.cpu().numpy(), v.numpy(), rtol=0, atol=5e-6, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_gpu_discriminator_gradients_match_reference_run_single_window(golden_dir):
+    import os
+    import torch.nn.functional as Fn
+    from video_frame_inpainting_amd.sn_discriminator import SNDiscriminator
+    z = np.load(os.path.join(golden_dir, 'sn_disc.npz'))
+    w0, u0 = _sn_group(z, 'disc_grad/w0/'), _sn_group(z, 'disc_grad/u0/')
+    want = _sn_group(z, 'disc_grad/grad/')
+    disc = SNDiscriminator((32, 32), 1, 3, 4, 3)
+    disc.load_state_dict(w0)
+    disc.to(DEV)
+    mods = dict(disc.named_modules())
+    for name, u in u0.items():
+        mods[name].u = u.to(DEV)
+    frames = torch.from_numpy(z['disc_grad/frames']).to(DEV).requires_grad_(True)
+    logits = disc(frames)
+    loss = Fn.binary_cross_entropy_with_logits(logits, torch.ones_like(logits))
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), z['disc_grad/logits'], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(float(loss.detach()), float(z['disc_grad/loss'][0]), rtol=1e-5)
+    for k, p in disc.named_parameters():
+        scale = float(want[k].abs().max())
+        assert scale > 1e-8, k
+        assert float((p.grad.cpu() - want[k]).abs().max()) <= 1e-3 * scale, (k, float((p.grad.cpu() - want[k]).abs().max()), scale)
+    gf = z['disc_grad/grad_frames']
+    assert float(np.abs(frames.grad.cpu().numpy() - gf).max()) <= 1e-3 * float(np.abs(gf).max())
