@@ -171,17 +171,27 @@ def conv_roofline(device):
             'note': 'achieved = Winograd-domain multiply-adds (direct-convolution flops / 2.25, unpadded K and C) per second'}
 
 
-def host_cpu_share(cap=16):
-    """Threads to use on the host: the scheduler affinity, the cgroup CPU quota and the GPU box's per-GPU CPU share (16),
-    whichever is smallest -- oversubscribing a 256-thread host from a 16-core share makes the CPU leg crawl."""
-    n = len(os.sched_getaffinity(0))
+GPU_BOX_CPU_SHARE = 16      # the pool's rule for a one-GPU box: "size worker pools to the box's CPU share (16 for one GPU)"
+
+
+def host_cpu_share(requested=None):
+    """Threads for the CPU leg and how they were chosen: the scheduler affinity, lowered by a cgroup CPU quota if there
+    is one, lowered to the pool's per-GPU CPU share (the host is shared: its other GPUs' users own the other cores) unless
+    ``--cpu-threads`` / TAI_CPU_THREADS asks for a number.  Returns (threads, description dict)."""
+    affinity = len(os.sched_getaffinity(0))
+    quota_cores = None
     try:
         quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
         if quota != 'max':
-            n = min(n, max(1, int(int(quota) / int(period))))
+            quota_cores = max(1, int(int(quota) / int(period)))
     except Exception:
         pass
-    return max(1, min(n, cap))
+    allowed = min(affinity, quota_cores) if quota_cores else affinity
+    requested = requested or int(os.environ.get('TAI_CPU_THREADS', '0')) or None
+    n = max(1, min(allowed, requested if requested else GPU_BOX_CPU_SHARE))
+    return n, {'sched_affinity': affinity, 'cgroup_quota_cores': quota_cores, 'requested': requested,
+               'gpu_box_cpu_share': GPU_BOX_CPU_SHARE,
+               'rule': 'min(affinity, cgroup quota, --cpu-threads if given else the one-GPU box share of 16)'}
 
 
 def _median_time(fn, n):
@@ -193,11 +203,11 @@ def _median_time(fn, n):
     return float(np.median(ts)), ts, out
 
 
-def cpu_baseline_and_parity(model, device, timed=3):
+def cpu_baseline_and_parity(model, device, timed=3, cpu_threads=None):
     """the CPU oracle at B = 1 and B = 8 (1 warm-up + `timed` forwards each, median), the
     sepconv loops alone, and GPU-vs-oracle parity on the B = 8 clips (full width, seeded weights and biases)."""
     from oracle import sepconv_oracle, tai_oracle
-    cores = host_cpu_share()
+    cores, cores_how = host_cpu_share(cpu_threads)
     torch.set_num_threads(cores)
     sepconv_oracle.set_num_threads(cores)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -233,7 +243,7 @@ def cpu_baseline_and_parity(model, device, timed=3):
             'b1': per_b[1], 'b8': per_b[n_clips],
             'sepconv_only': {'shape': [n_clips, C_, H_, W_], 'median_ms': round(s_med * 1e3, 2),
                              'gb_per_s': round(s_bytes / s_med / 1e9, 2), 'algorithmic_bytes': s_bytes},
-            'cpu_model': cpu_model, 'os_cpu_count': os.cpu_count(), 'sched_affinity': len(os.sched_getaffinity(0)),
+            'cpu_model': cpu_model, 'os_cpu_count': os.cpu_count(), 'threads_chosen_by': cores_how,
             'torch_threads': torch.get_num_threads()}
 
     keys = ('pred', 'pred_forward', 'pred_backward', 'interp_net_outputs_1', 'interp_net_outputs_2')
@@ -274,6 +284,8 @@ def launch_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=port, TAI_BENCH_RANK_PROCESS='1')
+        # this pool's host driver supports only dmabuf IPC: with the legacy mode RCCL's peer-buffer exchange fails with
+        # `hipIpcGetMemHandle: invalid argument` (the image exports 0 already; kept for a stripped environment)
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     failed = None
@@ -331,6 +343,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--miopen-find', action='store_true', help='let MIOpen benchmark its algorithms during warm-up')
     ap.add_argument('--rehearse-launch', action='store_true', help='CPU/gloo rehearsal of the rank launch only (tests)')
+    ap.add_argument('--rehearse-one-gpu', action='store_true',
+                    help='N ranks all on cuda:0 with gloo for the control plane: a rehearsal of the N-rank code path on a '
+                         'one-GPU box; the line is marked "rehearsal" and is never a measurement')
+    ap.add_argument('--cpu-threads', type=int, default=None, help='threads of the cpu_baseline leg (default: see host_cpu_share)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -339,7 +355,7 @@ def main():
         return rehearse_launch(args)
 
     _imports()
-    rank, world, local_rank = parallel.init_from_env()
+    rank, world, local_rank = parallel.init_from_env(**({'backend': 'gloo', 'local_rank': 0} if args.rehearse_one_gpu else {}))
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d' % (args.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     _native.lib()                                   # fail loudly if the HIP library is missing
@@ -410,6 +426,8 @@ def main():
                    'ranks': world, 'backend': ('rccl (torch.distributed "nccl")' if backend == 'nccl' else backend),
                    'weights': 'seeded N(0, 1/fan_in) weights and N(0, 0.01) biases (synthetic.seeded_init, seed %d)' % WEIGHT_SEED},
     }
+    if args.rehearse_one_gpu:
+        line['rehearsal'] = 'all %d ranks on one GPU, gloo control plane: NOT a measurement' % world
     if rank == 0:
         line['roofline'] = sepconv_roofline(device, B)
         log('roofline measured')
@@ -417,7 +435,7 @@ def main():
             line['roofline_conv'] = conv_roofline(device)
             log('convolution roofline measured')
         if world == 1 and not args.no_cpu_baseline:
-            base, parity = cpu_baseline_and_parity(model, device)
+            base, parity = cpu_baseline_and_parity(model, device, cpu_threads=args.cpu_threads)
             line['cpu_baseline'] = base
             line['parity'] = parity
         print(json.dumps(line), flush=True)

@@ -123,3 +123,27 @@ def test_random_draws_are_private_and_reproducible(tmp_path):
     assert vdata.ClipRecord('/x/v').spans is None
     with pytest.raises(RuntimeError):
         vdata.ClipRecord('/x/v 3_7')
+
+
+def test_loader_workers_draw_fresh_reproducible_streams_every_epoch(tmp_path):
+    """train.py re-iterates its DataLoader every epoch, so the workers are re-created every epoch: worker_init must give
+    them a stream that differs between epochs and workers (the reference reseeds the global ``random`` from the loader's
+    per-epoch base seed) and is reproducible from the loader's generator + the dataset's seed."""
+    fr = _frames(T=40, H=8, W=8)
+    np.save(tmp_path / 'c.npy', fr)
+    lst = tmp_path / 'l.txt'
+    lst.write_text(''.join('%s 1-40\n' % (tmp_path / 'c.npy') for _ in range(8)))
+
+    def run(loader_seed, ds_seed=3):
+        ds = vdata.ContiguousVideoClipDataset(3, str(lst), 5, True, True, (8, 8), False, (0, 0), seed=ds_seed)
+        g = torch.Generator().manual_seed(loader_seed)
+        loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=2, worker_init_fn=ds.worker_init, generator=g)
+        return [torch.cat([b['targets'] for b in loader]) for _ in range(2)]            # two epochs
+    e0, e1 = run(11)
+    assert e0.shape == (8, 5, 3, 8, 8)
+    assert not torch.equal(e0, e1)                          # a new epoch replays nothing
+    assert not torch.equal(e0[0:2], e0[2:4])                # the two workers draw differently (same line, different windows)
+    f0, f1 = run(11)
+    assert torch.equal(e0, f0) and torch.equal(e1, f1)      # reproducible
+    assert not torch.equal(run(12)[0], e0)                  # the loader's generator matters (train.py: opt.seed + 7 * rank)
+    assert not torch.equal(run(11, ds_seed=4)[0], e0)       # and so does the dataset's own seed

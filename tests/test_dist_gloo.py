@@ -75,6 +75,16 @@ def _worker(rank, world, port, out_dir):
         with torch.no_grad():
             for p in net.parameters():
                 p.sub_(0.1 * p.grad)
+    # a second backward() before the next zero_grad() would accumulate into buckets whose all-reduce is in flight: refused
+    reducer2.zero_grad()
+    net(xin).pow(2).mean().backward()
+    try:
+        net(xin).pow(2).mean().backward()
+    except RuntimeError as e:
+        assert 'one backward() per zero_grad()' in str(e)
+    else:
+        raise AssertionError('the second backward() must be refused')
+    reducer2.allreduce_()                                            # drains the first backward's collectives on both ranks
     opt.step()
     flat = torch.cat([p.detach().reshape(-1) for p in disc.parameters()] + [u.reshape(-1) for u in us])
     torch.save(flat, os.path.join(out_dir, 'rank%d.pt' % rank))

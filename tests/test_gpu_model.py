@@ -95,6 +95,38 @@ def test_full_width_tai_gray_matches_cpu_oracle():
         _assert_matches_oracle(g(), ref, GT, 'full width, hipGraph replay')
 
 
+def test_full_width_tai_color_matches_cpu_oracle():
+    """configs[3]'s model -- create_model('TAI_color') = TAIFillInModel(64, 3, 3, 51, num_block=4) (create_model.py:29-30),
+    256x256 BGR, K = F = 3, T = 5 -- at its real width against the CPU oracle on one clip: the 256^2 Winograd layer
+    shapes, the three-channel sepconv kernel (sepconv_forward_asm_c3) at [5,3,256,256], the decoder that never injects
+    the time ratio (tai.py:213-217 with num_block 4), the BGR -> gray temporal differences."""
+    m = synthetic.seeded_init(vfi.create_model('TAI_color'), 0)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    clips = synthetic.make_clips(1, 11, 3, 256, 256, synthetic.SEEDS['cfg4'])
+    P, GT, Fo = (torch.from_numpy(x) for x in synthetic.split_clip(clips, 3, 5, 3))
+    with torch.no_grad():
+        ref = tai_oracle.tai_forward(sd, 3, 4, 51, 5, P, Fo)
+        m.to(DEV).eval()
+        out = m(5, P.to(DEV), Fo.to(DEV))
+        _assert_matches_oracle(out, ref, GT, 'TAI_color full width, eager')
+        g = GraphedForward(m, 5, P.to(DEV), Fo.to(DEV))
+        _assert_matches_oracle(g(), ref, GT, 'TAI_color full width, hipGraph replay')
+
+
+def test_full_width_tai_gray_long_gap_matches_cpu_oracle():
+    """configs[4]: TAI_gray at full width with T = 10 middle frames (alt_T), K = F = 5, one clip."""
+    m = synthetic.seeded_init(vfi.create_model('TAI_gray'), 0)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    clips = synthetic.make_clips(1, 20, 1, 128, 128, synthetic.SEEDS['cfg5'])
+    P, GT, Fo = (torch.from_numpy(x) for x in synthetic.split_clip(clips, 5, 10, 5))
+    with torch.no_grad():
+        ref = tai_oracle.tai_forward(sd, 1, 5, 51, 10, P, Fo)
+        m.to(DEV).eval()
+        out = m(10, P.to(DEV), Fo.to(DEV))
+        assert out['pred'].shape == (1, 10, 1, 128, 128)
+        _assert_matches_oracle(out, ref, GT, 'TAI_gray T=10 full width')
+
+
 def test_derived_weights_follow_in_place_weight_writes():
     """conv_ops caches Winograd-domain / flipped weights per tensor version: a write that moves the version
     counter is seen by itself; a write through .data needs conv_ops.invalidate_derived (weights_init, the replica

@@ -162,19 +162,25 @@ def test_sn_linear_single_logit_matches_linear():
 
 
 @pytest.mark.gpu
-def test_graphed_update_matches_the_eager_update(tmp_path):
-    """train_step with graph_step (two eager updates, then one captured update replayed) against the same four updates
-    run eagerly on an identically initialised environment: same loss terms every update and the same weights at the
-    end, to fp32 rounding (MIOpen's weight-gradient kernels accumulate with atomics: not bit-reproducible)."""
+def test_graphed_update_matches_the_eager_update(tmp_path, monkeypatch):
+    """train_step with graph_step (two eager updates, then one captured update replayed) against the same update run
+    eagerly.  The comparison is made where it is well-posed: on the GRADIENTS of one update that both environments start
+    from bit-identical state (weights, Adam moments and step counter, spectral-norm u vectors copied in place from the
+    eager environment into the captured one's static tensors), before Adam turns rounding-level gradient elements into
+    +-lr steps.  Every 3x3 layer is forced onto the in-tree Winograd kernels (fixed summation order) so the generator's
+    gradients are reproducible; the discriminator's 4x4 stride-2 layers stay on MIOpen (atomics in its weight gradient),
+    hence its own, looser bound.  Then: every parameter moved in that update, by at most Adam's bound."""
+    from video_frame_inpainting_amd import conv_ops
+    monkeypatch.setattr(conv_ops, 'WINO_MIN_WORKGROUPS', 0)
     K = T = F = 3
     H = W = 64
     B = 2
+    LR = 1e-3
     clips = torch.from_numpy(synthetic.make_clips(4 * B, K + T + F, 1, H, W, synthetic.SEEDS['cfg3']))
     envs = {}
-    history = {}
     for mode in ('eager', 'graph'):
         model = vfi.TAIFillInModel(16, 1, 3, 51, num_block=5, kf_dim=16)
-        env = TAITrainingEnvironment(model, str(tmp_path / mode), 'exp', [H, W], 1, ALPHA, BETA, 1e-3, 0.5, 16, IP, DISC_T, K, T, F,
+        env = TAITrainingEnvironment(model, str(tmp_path / mode), 'exp', [H, W], 1, ALPHA, BETA, LR, 0.5, 16, IP, DISC_T, K, T, F,
                                      [0, 0], device=DEV, graph_step=True)
         if mode == 'eager':
             env.STEP_GRAPH_WARMUP = 10 ** 9            # same optimizer arithmetic (Adam's counter on the device), never captured
@@ -186,39 +192,112 @@ def test_graphed_update_matches_the_eager_update(tmp_path):
                 m.u = torch.randn(1, m.weight.size(0), generator=g).to(DEV)
         env.K, env.T, env.F = K, T, F
         env.train()
-        history[mode] = []
-        for step in range(4):
+        for step in range(3):                          # graph: two eager updates, then capture + first replay
             P, GT, Fo = synthetic.split_clip(clips[step * B:(step + 1) * B], K, T, F)
             env.train_step(P, Fo, GT)
-            history[mode].append(env.get_current_errors())
         envs[mode] = env
-    state = envs['graph']._step_graphs
-    assert len(state) == 1 and 'graph' in next(iter(state.values()))                     # updates 3 and 4 were replays
-    assert all('graph' not in v for v in envs['eager']._step_graphs.values())
-    for step in range(4):
-        for k, v in history['eager'][step].items():
-            assert abs(history['graph'][step][k] - v) <= 5e-4 * max(abs(v), 1e-3), (step, k, history['graph'][step][k], v)
+    eager, graph = envs['eager'], envs['graph']
+    state = graph._step_graphs
+    assert len(state) == 1 and 'graph' in next(iter(state.values()))
+    assert all('graph' not in v for v in eager._step_graphs.values())
+
+    # --- identical starting state for update 4, written IN PLACE into the tensors the captured graph reads
+    with torch.no_grad():
+        for part in ('generator', 'discriminator'):
+            src, dst = getattr(eager, part), getattr(graph, part)
+            for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+                b.copy_(a)
+            for (name, ms), (_, md) in zip(src.named_modules(), dst.named_modules()):
+                if hasattr(ms, 'Ip'):
+                    md.u.copy_(ms.u)
+        for o_src, o_dst in ((eager.optimizer_G, graph.optimizer_G), (eager.optimizer_D, graph.optimizer_D)):
+            for ps, pd in zip(o_src.param_groups[0]['params'], o_dst.param_groups[0]['params']):
+                ss, sd = o_src.state.get(ps, {}), o_dst.state.get(pd, {})
+                assert set(ss) == set(sd)
+                for key, v in ss.items():
+                    sd[key].copy_(v)
+    conv_ops.invalidate_derived()
+    before = {part: {k: v.detach().clone() for k, v in getattr(graph, part).named_parameters()} for part in ('generator', 'discriminator')}
+
+    P, GT, Fo = synthetic.split_clip(clips[3 * B:4 * B], K, T, F)
+    eager.train_step(P, Fo, GT)
+    graph.train_step(P, Fo, GT)                         # a replay
+    torch.cuda.synchronize()
+
+    # --- loss terms of that update
+    e_err, g_err = eager.get_current_errors(), graph.get_current_errors()
+    for k, v in e_err.items():
+        assert abs(g_err[k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, g_err[k], v)
+    # --- gradients before Adam (p.grad still holds them after the step)
+    report = []
+    for part, tol in (('generator', 2e-4), ('discriminator', 2e-3)):
+        for (k, pe), (_, pg) in zip(getattr(eager, part).named_parameters(), getattr(graph, part).named_parameters()):
+            if pe.grad is None:
+                assert pg.grad is None and k.startswith('merge_residual1'), k       # never evaluated (tai.py:224-226)
+                continue
+            scale = float(pe.grad.abs().max())
+            err = float((pg.grad - pe.grad).abs().max())
+            report.append('%-14s %-44s max|g| %.3e err/max %.2e' % (part, k, scale, err / max(scale, 1e-30)))
+            assert scale > 0, report[-1]
+            assert err <= tol * scale, report[-1]
+    print('\n'.join(report))
+    # --- every parameter moved, by no more than Adam can move it in one update (lr x bias-corrected ratio <~ a few lr)
     for part in ('generator', 'discriminator'):
-        ref = getattr(envs['eager'], part).state_dict()
-        for k, v in getattr(envs['graph'], part).state_dict().items():
-            # Adam normalises every gradient element by its own running magnitude: where a gradient is at rounding level
-            # (MIOpen's atomics reorder sums from run to run) the update's direction is noise, so single elements may
-            # differ by up to lr x updates = 4e-3 each way (eight runs: max 1.5e-5 .. 3.4e-3, mean over a tensor <= 1.5e-5, loss terms <= 3.6e-5
-            # relative); anything systematic (a stale weight, a skipped update) is far larger
-            diff = (v - ref[k]).abs()
-            assert float(diff.max()) <= 8e-3, (part, k, float(diff.max()))           # 2 x lr x updates: Adam's reach
-            assert float(diff.mean()) <= 2e-4, (part, k, float(diff.mean()))         # a missed update moves every element by ~lr = 1e-3
+        for k, p in getattr(graph, part).named_parameters():
+            if p.grad is None:
+                continue
+            delta = (p.detach() - before[part][k]).abs()
+            if part == 'discriminator' and k.endswith('weight'):
+                continue        # also renormalised in place by 3 x 7 spectral-norm passes: checked against the eager side below
+            assert float(delta.max()) > 0.1 * LR, (part, k, float(delta.max()))
+            assert float(delta.max()) <= 5 * LR, (part, k, float(delta.max()))
+        for (k, pe), (_, pg) in zip(getattr(eager, part).named_parameters(), getattr(graph, part).named_parameters()):
+            # same start, same gradients to rounding: the updated weights agree except where a gradient element is at
+            # rounding level (Adam normalises each element by its own magnitude), so the MEAN difference is tiny
+            assert float((pe.detach() - pg.detach()).abs().mean()) <= 2e-5, (part, k)
     # after replays an eager forward sees the CURRENT weights (derived Winograd filters rebuilt)
     P, GT, Fo = synthetic.split_clip(clips[:B], K, T, F)
     outs = []
-    for mode in ('eager', 'graph'):
-        env = envs[mode]
+    for env in (eager, graph):
         env.eval()
         with torch.no_grad():
             outs.append(env.generator(T, P.to(DEV), Fo.to(DEV))['pred'])
-    assert float((outs[0] - outs[1]).abs().max()) <= 5e-3
-    # ... and not the weights of the update before (what the captured Winograd filters were computed from)
     assert torch.isfinite(outs[1]).all()
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-3
+
+
+@pytest.mark.gpu
+def test_captured_workspace_survives_a_larger_eager_request():
+    """conv_ops keeps one growing scratch buffer per device for the weight-gradient kernels; a captured graph bakes in its
+    pointer.  A later eager call with a larger request used to REPLACE the buffer and hand the old block back to the
+    allocator while replays still wrote partial sums into it: superseded buffers are now kept alive once a
+    capture has seen them."""
+    from video_frame_inpainting_amd import conv_ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 64, 32, 32, generator=g).to(DEV)
+    gy = torch.randn(4, 64, 32, 32, generator=g).to(DEV)
+    conv_ops._WRW_WORKSPACE.current.pop(x.device, None)         # start from no workspace on this device
+    want = conv_ops.wino_weight_grad(x, gy)
+    assert want is not None
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        got = conv_ops.wino_weight_grad(x, gy)
+    small_ws = conv_ops._WRW_WORKSPACE.current[x.device]
+    xb = torch.randn(32, 64, 64, 64, generator=g).to(DEV)
+    gb = torch.randn(32, 64, 64, 64, generator=g).to(DEV)
+    conv_ops.wino_weight_grad(xb, gb)                            # larger request: a new buffer ...
+    assert conv_ops._WRW_WORKSPACE.current[x.device].data_ptr() != small_ws.data_ptr()
+    assert any(t.data_ptr() == small_ws.data_ptr() for t in conv_ops._WRW_WORKSPACE.retired)     # ... the old one retired, not freed
+    del small_ws
+    junk = [torch.full((1 << 20,), float('nan'), device=DEV) for _ in range(64)]      # whatever the allocator hands out now
+    graph.replay()
+    for t in junk:
+        t.fill_(float('nan'))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert all(bool(torch.isnan(t).all()) for t in junk)         # the replay wrote into nobody else's memory
 
 
 # ---- reference-run pins (tests/golden/sn_disc.npz: the reference's own SNDiscriminator.py run on CPU by make_golden.py) ----

@@ -616,6 +616,7 @@ def main():
                 ('TAI_FWD_ROWLOOP_ASM_LA4', 4, 5, False, False),          # 4 chunks ahead, 5 buffers (v[220:239])
                 ('TAI_FWD_ROWLOOP_ASM_NOVM', 3, 4, True, False),          # timing experiment: no v-ring wait
                 ('TAI_FWD_ROWLOOP_ASM_NOLGKM', 3, 4, False, True)]        # timing experiment: no window waits
+    final, out = out, out + '.tmp.%d' % os.getpid()      # written beside the target, renamed over it at the end
     with open(out, 'w') as f:
         f.write('// GENERATED by tools/gen_fwd_asm.py -- do not edit.  Register map and schedule: see the generator.\n')
         f.write('#define TAI_FWD_ROWLOOP_RING_SLOTS %d\n' % SLOTS)
@@ -673,7 +674,8 @@ def main():
         clob = ['v%d' % r for r in list(range(204, 212)) + list(range(220, 240)) + [243, 244, 245, 246, 247, 248]]
         clob += ['s%d' % r for r in range(64, 71)] + ['scc', 'memory']   # m0 is written too; hipcc reloads it before each of its own uses
         f.write('#define TAI_FWD_ROWLOOP_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob))
-    print('wrote %s' % out)
+    os.replace(out, final)
+    print('wrote %s' % final)
 
 
 if __name__ == '__main__':

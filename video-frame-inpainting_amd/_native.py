@@ -13,8 +13,15 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, 'libtai_sepconv.so')
 HEADER = os.path.join(_ROOT, 'include', 'tai_sepconv.h')
-SOURCES = [os.path.join(_PKG, 'csrc', f) for f in
-           ('sepconv_capi.hip', 'sepconv_fwd.hip.inc', 'sepconv_bwd.hip.inc', 'sepconv_fwd_rowloop.inc', 'upsample.hip.inc', 'bias_act.hip.inc', 'thin_conv.hip.inc', 'wino_conv.hip.inc')]
+CSRC = os.path.join(_PKG, 'csrc')
+MAIN_SOURCE = os.path.join(CSRC, 'sepconv_capi.hip')          # the one translation unit; it #includes every *.inc
+GENERATED = os.path.join(CSRC, 'sepconv_fwd_rowloop.inc')     # written by tools/gen_fwd_asm.py
+
+
+def sources():
+    """Every file under csrc/: the staleness check covers whatever the translation unit includes, listed or not."""
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.startswith('.'))
+
 
 _lib = None
 
@@ -39,19 +46,25 @@ def build(force=False, verbose=False, timing=False):
     the timing experiments (forward variants >= 100, Winograd timeline skip levels) that the shipped library leaves out;
     only tools/ links or loads it."""
     out = TIMING_LIB_PATH if timing else LIB_PATH
-    newest = max(os.path.getmtime(p) for p in SOURCES + [HEADER])
+    regenerate()
+    newest = max(os.path.getmtime(p) for p in sources() + [HEADER])
     if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
         return out
-    gen = os.path.join(_ROOT, 'tools', 'gen_fwd_asm.py')
-    if os.path.exists(gen) and os.path.getmtime(gen) > os.path.getmtime(SOURCES[3]):
-        subprocess.check_call(['python3', gen], stdout=subprocess.DEVNULL)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-slp-vectorize', '-w',
-           '-I' + os.path.join(_ROOT, 'include'), '-o', out, SOURCES[0]] + (['-DTAI_TIMING_VARIANTS'] if timing else [])
+           '-I' + os.path.join(_ROOT, 'include'), '-o', out, MAIN_SOURCE] + (['-DTAI_TIMING_VARIANTS'] if timing else [])
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
     return out
+
+
+def regenerate():
+    """Re-run the row-loop generator when it is newer than its output.  The generator writes a temporary file and renames
+    it over the target, so a concurrent hipcc never reads a half-written include."""
+    gen = os.path.join(_ROOT, 'tools', 'gen_fwd_asm.py')
+    if os.path.exists(gen) and (not os.path.exists(GENERATED) or os.path.getmtime(gen) > os.path.getmtime(GENERATED)):
+        subprocess.check_call(['python3', gen], stdout=subprocess.DEVNULL)
 
 
 def lib():

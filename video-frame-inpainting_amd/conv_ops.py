@@ -283,7 +283,26 @@ def _zero_bias(n, device):
     return z
 
 
-_WRW_WORKSPACE = {}
+class _GrowingWorkspace(object):
+    """Per-device fp32 scratch that grows to the largest request.  A captured graph (environments.train_step with
+    graph_step) bakes the buffer's raw pointer into its kernel nodes, so once any request has been served under capture a
+    superseded buffer is retired to a keep-alive list instead of being released: a later, larger eager request must not
+    hand the old block back to the caching allocator while replays still write partial sums into it."""
+
+    def __init__(self):
+        self.current, self.retired, self.captured = {}, [], False
+
+    def get(self, device, floats):
+        self.captured = self.captured or torch.cuda.is_current_stream_capturing()
+        ws = self.current.get(device)
+        if ws is None or ws.numel() < floats:
+            if ws is not None and self.captured:
+                self.retired.append(ws)
+            ws = self.current[device] = torch.empty(floats, dtype=torch.float32, device=device)
+        return ws
+
+
+_WRW_WORKSPACE = _GrowingWorkspace()
 
 
 def wino_weight_grad(x, grad_out, with_bias=False, window=None):
@@ -299,9 +318,7 @@ def wino_weight_grad(x, grad_out, with_bias=False, window=None):
     floats = L.tai_conv3x3_wino_wrw_workspace_floats(N, Ci, Co, H, W)
     if floats < 0 or N * Ci * x.shape[2] * x.shape[3] >= 2 ** 29:
         return None
-    ws = _WRW_WORKSPACE.get(x.device)
-    if ws is None or ws.numel() < floats:
-        ws = _WRW_WORKSPACE[x.device] = torch.empty(floats, dtype=torch.float32, device=x.device)
+    ws = _WRW_WORKSPACE.get(x.device, floats)
     dw = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=x.device)
     db = torch.empty(Co, dtype=torch.float32, device=x.device) if with_bias else None
     with torch.cuda.device(x.device):
@@ -405,16 +422,14 @@ class _WinoConvKxK(torch.autograd.Function):
         return gx, gw, gb, None
 
 
-_THIN_WORKSPACE = {}
+_THIN_WORKSPACE = _GrowingWorkspace()
 
 
 def thin_weight_grad(big, thin, k):
     """(dw [Cb, k, k], db [Cb]) with dw[cb][a][b] = sum of big[n, cb, y, x] * thin[n, 0, y + a - k/2, x + b - k/2] and
     db[cb] = sum of big[n, cb]: one pass over ``big`` (tai_thin_conv_wrw)."""
     N, Cb, H, W = big.shape
-    ws = _THIN_WORKSPACE.get(big.device)
-    if ws is None or ws.numel() < N * Cb * 32:
-        ws = _THIN_WORKSPACE[big.device] = torch.empty(N * Cb * 32, dtype=torch.float32, device=big.device)
+    ws = _THIN_WORKSPACE.get(big.device, N * Cb * 32)
     dw = torch.empty((Cb, k, k), dtype=torch.float32, device=big.device)
     db = torch.empty(Cb, dtype=torch.float32, device=big.device)
     with torch.cuda.device(big.device):

@@ -175,10 +175,15 @@ class ContiguousVideoClipDataset(data.Dataset):
         self.seq_len = seq_length
         self.backwards, self.flip, self.resample_on_fail = backwards, flip, resample_on_fail
         self.reader = _ClipReader(c_dim, image_size, padding_size)
-        self.rng = random.Random(seed)
+        self._seed = int(seed)
+        self.rng = random.Random(self._seed)
 
     def worker_init(self, worker_id):
-        self.rng = random.Random((self.rng.random(), worker_id))
+        """DataLoader ``worker_init_fn``.  Inside a worker ``torch.initial_seed()`` is the loader's base seed + worker id,
+        and the base seed is drawn afresh from the loader's generator every time the loader is iterated -- so, as in the
+        reference (whose workers reseed the global ``random`` from that same base seed), every epoch and every worker
+        gets its own stream, reproducible from the loader's generator and this dataset's seed."""
+        self.rng = random.Random(int(torch.initial_seed()) ^ (self._seed << 20))
 
     def __len__(self):
         return len(self.files)

@@ -18,16 +18,13 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, local_rank=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (set by torch.distributed.run).
-    Returns (rank, world_size, local_rank); a single un-launched process gets (0, 1, 0) and no group."""
+    Returns (rank, world_size, local_rank); a single un-launched process gets (0, 1, 0) and no group.  ``backend`` and
+    ``local_rank`` override what the environment implies (tools/rehearse_ranks_one_gpu.py: gloo, every rank on cuda:0)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if os.environ.get('TAI_REHEARSE_ON_ONE_GPU') == '1':
-        # rehearsal of the N-rank code path on a one-GPU box: every rank drives cuda:0 and the (tiny) control-plane
-        # collectives go over gloo.  Never used for measurements.
-        backend, local_rank = 'gloo', 0
+    local_rank = int(os.environ.get('LOCAL_RANK', '0')) if local_rank is None else local_rank
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
@@ -151,6 +148,11 @@ class GradAllReducer(object):
         if not self._armed:
             return
         b = self._bucket_of[p]
+        if world_size() > 1 and (self._pending[b] <= 0 or self._work[b] is not None):
+            # a second backward() since zero_grad(): this gradient was just accumulated into a bucket whose all-reduce is
+            # already in flight (or complete) -- the collective's result would be undefined
+            raise RuntimeError('GradAllReducer: a gradient arrived for a bucket whose all-reduce was already launched; the '
+                               'overlapped form supports exactly one backward() per zero_grad()')
         self._pending[b] -= 1
         if self._pending[b] == 0:
             self._launch(b)
