@@ -113,10 +113,49 @@ def sepconv_roofline(device, B, iters=200, warmup=20):
             traffic = rec.get('hbm_bytes_per_launch') if same else None
         except Exception:
             traffic = None
+    del graph, out, inp, v, h
     return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'kernel': 'sepconv_forward',
             'shape': [B, C_, H_, W_], 'us_per_launch': round(us, 2), 'us_per_launch_first_pass': round(us_first, 2),
-            'algorithmic_bytes': nbytes}
+            'algorithmic_bytes': nbytes,
+            'inputs': 'Infinity-Cache-warm: the same %.0f MB of tap planes re-read by back-to-back graph replays fit the 256 MiB '
+                      'Infinity Cache (FETCH_SIZE counts its hits: `traffic` is fabric traffic); us_per_launch_first_pass = the '
+                      'first 200 launches right after the model steps' % (2 * B * ks * H_ * W_ * 4 / 1e6),
+            'in_model': sepconv_in_model_roofline(device, B)}
+
+
+def sepconv_in_model_roofline(device, B, reps=10):
+    """The launch the model makes: all T time steps in one, [T*B,1,128,128] (grid 655360 at B = 32), its 2 x 534 MB of tap
+    planes just written by the kernel network's last 51 -> 51 convolutions (4x the Infinity Cache: they come from HBM).
+    Timed as in the model's stream order -- the two producing Winograd convolutions, then the sepconv -- with HIP events
+    around the sepconv alone, kernels queued back to back.  profiles/ holds rocprofv3's duration of the same launch
+    inside the replayed forward (grid 655360) and the in-kernel span / shader clock from the tools build."""
+    ks, N = 51, T_ * B
+    g = torch.Generator().manual_seed(8)
+    inp = (torch.rand(N, C_, H_ + ks - 1, W_ + ks - 1, generator=g) * 2 - 1).to(device)
+    x = (torch.randn(N, ks, H_, W_, generator=g) * 0.5).to(device)
+    w = (torch.randn(ks, ks, 3, 3, generator=g) * (0.3 / (ks * 9) ** 0.5)).to(device)
+    b = (torch.randn(ks, generator=g) * 0.01).to(device)
+    v, h = torch.empty_like(x), torch.empty_like(x)
+    from video_frame_inpainting_amd import conv_ops
+    f = vfi.SeparableConvolution.apply
+    pairs = []
+    with torch.no_grad():
+        for rep in range(reps + 3):
+            conv_ops.conv_bias_act(x, w, b, 1, None, out=v)
+            conv_ops.conv_bias_act(x, w, b, 1, None, out=h)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); f(inp, v, h, ks); e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b2) * 1e3 for a, b2 in pairs[3:])
+    us = float(np.mean(ts))
+    nbytes = sc.forward_bytes(N, C_, H_, W_, ks)
+    log('sepconv forward, in-model launch [%d,1,128,128] behind its tap-producing convolutions: mean %.1f us (min %.1f, max %.1f)' % (N, us, ts[0], ts[-1]))
+    return {'shape': [N, C_, H_, W_], 'us_per_launch': round(us, 1), 'us_min': round(ts[0], 1), 'us_max': round(ts[-1], 1),
+            'achieved': round(nbytes / us / 1e3, 1), 'frac': round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4), 'algorithmic_bytes': nbytes,
+            'inputs': 'HBM: %.0f MB of tap planes written by the two preceding convolutions, 4x the Infinity Cache' % (2 * N * ks * H_ * W_ * 4 / 1e6),
+            'timing': 'HIP events around the launch, %d repetitions, mean (event overhead ~5 us included)' % reps}
 
 
 # (N, C, K, H, W, calls per forward) of the 3x3 convolutions of configs[1] (TAI_gray, 32 clips: both directions batched to
@@ -267,6 +306,123 @@ def cpu_baseline_and_parity(model, device, timed=3, cpu_threads=None):
     return base, parity
 
 
+def secondary_configs(device):
+    """configs[3] (TAI_color 256x256 BGR, K=F=3, T=5, batch 16) and configs[4] (TAI_gray T=10, batch 32) end to end on one
+    GPU -- hipGraph replay, 2 warm + 3 timed -- and the sepconv forward at configs[3]'s shape against both of its ceilings
+    (36 flop/B: above the ridge, so the fp32 vector peak is the one that binds)."""
+    res = {}
+    for name, key, B, C, H, W, K, T, F in (('configs[3]', 'TAI_color', 16, 3, 256, 256, 3, 5, 3), ('configs[4]', 'TAI_gray', 32, 1, 128, 128, 5, 10, 5)):
+        m = synthetic.seeded_init(vfi.create_model(key), WEIGHT_SEED).to(device).eval()
+        clips = synthetic.make_clips(B, K + T + F, C, H, W, synthetic.SEEDS['cfg4' if C == 3 else 'cfg5'])
+        P, _, Fo = (torch.from_numpy(x).to(device) for x in synthetic.split_clip(clips, K, T, F))
+        g = GraphedForward(m, T, P, Fo, warmup=1)
+        for _ in range(2):
+            g()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            g()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        res[name] = {'model': key, 'clips': B, 'frame': [C, H, W], 'K_T_F': [K, T, F], 'ms_per_step': round(dt * 1e3, 2),
+                     'frames_per_s': round(B * T / dt, 1)}
+        log('%s: %.1f ms per step, %.1f frames/s' % (name, dt * 1e3, B * T / dt))
+        del g, m, P, Fo
+        torch.cuda.empty_cache()
+    # the three-channel sepconv forward at configs[3]'s launch shape [T*B = 80, 3, 256, 256] would be 2.3 GB of taps; the
+    # per-time-step shape [16,3,256,256] is the one SURVEY.md 8(a) tabulates
+    ks, B, C, H, W = 51, 16, 3, 256, 256
+    gen = torch.Generator().manual_seed(7)
+    inp = (torch.rand(B, C, H + ks - 1, W + ks - 1, generator=gen) * 2 - 1).to(device)
+    v = (torch.randn(B, ks, H, W, generator=gen) * 0.1).to(device)
+    h = (torch.randn(B, ks, H, W, generator=gen) * 0.1).to(device)
+    f = vfi.SeparableConvolution.apply
+    with torch.no_grad():
+        for _ in range(5):
+            f(inp, v, h, ks)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            f(inp, v, h, ks)
+        e1.record(); e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    nb = sc.forward_bytes(B, C, H, W, ks)
+    flops = 2.0 * B * C * H * W * (ks * ks + ks)
+    res['sepconv_forward_c3'] = {'shape': [B, C, H, W], 'us_per_launch': round(us, 1), 'algorithmic_bytes': nb,
+                                 'hbm': {'achieved_GBps': round(nb / us / 1e3, 1), 'frac': round(nb / us / 1e3 / HBM_PEAK_GBS, 4)},
+                                 'fp32_vector': {'achieved_TFLOPs': round(flops / us / 1e6, 1), 'peak': MFMA_F32_PEAK_TFLOPS,
+                                                 'frac': round(flops / us / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
+                                                 'flops': 'factored form 2 B C H W (ks^2 + ks)'}}
+    del inp, v, h
+    torch.cuda.empty_cache()
+    return res
+
+
+_TRAIN_KERNEL_GROUPS = (('winograd weight gradient', ('wino::wrw',)), ('winograd forward / input gradient', ('wino::conv3x3',)),
+                        ('sepconv forward', ('fwd::sepconv',)), ('sepconv backward', ('bwd::',)), ('spectral norm', ('snorm::',)),
+                        ('MIOpen / rocBLAS', ('miopen', 'MIOpen', 'igemm', 'Cijk', 'gemm', 'naive_conv', 'SubTensor', 'batched_transpose', 'Igemm')),
+                        ('other in-tree kernels', ('thin::', 'ups::', 'bact::', 'lstm::', 'pool::', 'wino::')),
+                        ('optimizer (Adam)', ('multi_tensor', 'adam', 'Adam')))
+
+
+def train_step_leg(device, B=32, timed=3):
+    """configs[2]'s per-GPU work: one TAI_gray update (G then D, GAN + reconstruction losses, Adam, fp32) at 32 clips of
+    128x128, K=T=F=5 -- eager launches as train.py issues them; 2 warm-up updates, `timed` timed; then one update under
+    torch.profiler for the kernel-time split."""
+    import contextlib
+    import tempfile
+    from video_frame_inpainting_amd.environments import create_training_environment
+    with contextlib.redirect_stdout(sys.stderr):
+        env = create_training_environment(vfi.create_model('TAI_gray'), 1, tempfile.mkdtemp(prefix='tai_bench_'), 'bench', 5, 5, 5, [H_, W_],
+                                          1.0, 0.02, 1e-4, 0.5, 64, 3, 3, [0, 0], device=device)
+    env.sync_replicas()
+    clips = torch.from_numpy(synthetic.make_clips(B, K_ + T_ + F_, C_, H_, W_, synthetic.SEEDS['cfg3']))
+    P, GT, Fo = synthetic.split_clip(clips, K_, T_, F_)
+
+    def step():
+        env.K, env.T, env.F = K_, T_, F_
+        env.train()
+        env.train_step(P, Fo, GT)
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    log('training: first update %.1f s' % (time.perf_counter() - t0))
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / timed
+    log('training: %.1f ms per update at %d clips' % (dt * 1e3, B))
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        step()
+        torch.cuda.synchronize()
+    split, total, launches = {}, 0.0, 0
+    for e in prof.key_averages():
+        us = getattr(e, 'self_device_time_total', None)
+        if us is None:
+            us = e.self_cuda_time_total
+        if not us:
+            continue
+        group = next((gname for gname, pats in _TRAIN_KERNEL_GROUPS if any(p in e.key for p in pats)), 'element-wise / copy / other')
+        split[group] = split.get(group, 0.0) + us / 1e3
+        total += us / 1e3
+        launches += e.count
+    errs = env.get_current_errors()
+    out = {'workload': 'configs[2] per-GPU share: TAI_gray G+D update, %d clips 128x128 K=T=F=5, alpha 1 beta 0.02 lr 1e-4 Ip 3 disc_t 3 df_dim 64, fp32' % B,
+           'ms_per_update': round(dt * 1e3, 1), 'clips_per_s': round(B / dt, 1), 'updates_timed': timed,
+           'kernel_ms': {k: round(v, 1) for k, v in sorted(split.items(), key=lambda kv: -kv[1])},
+           'kernel_ms_total': round(total, 1), 'kernel_launches': int(launches),
+           'peak_memory_GB': round(torch.cuda.max_memory_allocated(device) / 1e9, 1),
+           'losses_finite': bool(all(np.isfinite(v) for v in errs.values()))}
+    del env
+    torch.cuda.empty_cache()
+    return out
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -346,6 +502,7 @@ def main():
     ap.add_argument('--rehearse-one-gpu', action='store_true',
                     help='N ranks all on cuda:0 with gloo for the control plane: a rehearsal of the N-rank code path on a '
                          'one-GPU box; the line is marked "rehearsal" and is never a measurement')
+    ap.add_argument('--no-extras', action='store_true', help='skip the secondary-config and training-update legs (extra keys of the line)')
     ap.add_argument('--cpu-threads', type=int, default=None, help='threads of the cpu_baseline leg (default: see host_cpu_share)')
     args = ap.parse_args()
 
@@ -438,6 +595,19 @@ def main():
             base, parity = cpu_baseline_and_parity(model, device, cpu_threads=args.cpu_threads)
             line['cpu_baseline'] = base
             line['parity'] = parity
+        if world == 1 and B == 32 and not args.no_extras:
+            # extra keys, after the timed region: the other BASELINE.json configs this GPU can run, so that the driver's
+            # record carries them (they are not the metric)
+            del model, P, Fo
+            if not args.no_graph:
+                del graphed, step
+            torch.cuda.empty_cache()
+            for key, leg in (('secondary', secondary_configs), ('train_step', train_step_leg)):
+                try:
+                    line[key] = leg(device)
+                except Exception as e:          # an extra leg must never cost the headline line
+                    line[key] = {'error': '%s: %s' % (type(e).__name__, e)}
+                    log('%s leg failed: %r' % (key, e))
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""The sepconv forward launches INSIDE the captured bi-TAI forward (configs[1]: TAI_gray, 32 clips, hipGraph replay):
+kernel span and shader clock from in-kernel stamps (tools build, forward variant 109 = the default kernel writing stamps
+instead of pixels; everything before the sepconv -- the whole model -- runs as in production).
+
+Usage: TAI_NATIVE_TIMING_LIB=1 python tools/sepconv_inmodel_clock.py"""
+import os
+import sys
+os.environ['TAI_NATIVE_TIMING_LIB'] = '1'
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import video_frame_inpainting_amd as vfi
+from video_frame_inpainting_amd import _native, synthetic
+from video_frame_inpainting_amd.graph import GraphedForward
+
+dev = torch.device('cuda:0')
+L = _native.lib()
+H = W = 128
+
+
+def read_stamps(t, B):
+    nblk = B * (H // 16)
+    r = t.contiguous().view(torch.int64).reshape(-1)[:nblk * 64].cpu().numpy().reshape(nblk * 8, 8)
+    t0, t3, c0, c1 = r[:, 0], r[:, 3], r[:, 5], r[:, 6]
+    ghz = ((c1 - c0) / np.maximum(t3 - t0, 1)) * 0.1
+    return (t3.max() - t0.min()) / 100.0, float(np.median(ghz)), float(np.median((t3 - t0) / 100.0)), int(t0.min()), int(t3.max())
+
+
+def main():
+    B, T = 32, 5
+    model = synthetic.seeded_init(vfi.create_model('TAI_gray'), 0).to(dev).eval()
+    clips = synthetic.make_clips(B, 15, 1, H, W, synthetic.SEEDS['cfg2'])
+    P, _, Fo = (torch.from_numpy(a).to(dev) for a in synthetic.split_clip(clips, 5, 5, 5))
+    with torch.no_grad():
+        model(T, P, Fo); model(T, P, Fo)
+        torch.cuda.synchronize()
+        L.tai_sepconv_set_forward_variant(109)
+        graphed = GraphedForward(model, T, P, Fo, warmup=1)
+        L.tai_sepconv_set_forward_variant(0)
+        for rep in range(8):
+            out = graphed()
+            torch.cuda.synchronize()
+            # tb(): [T*B, ...] viewed [T, B, ...] and transposed; undo it to get the launch's own output buffer
+            rows = []
+            for key in ('interp_net_outputs_1', 'interp_net_outputs_2'):
+                base = out[key].transpose(0, 1).contiguous().view(T * B, 1, H, W)
+                rows.append(read_stamps(base, T * B))
+            gap = (rows[1][3] - rows[0][4]) / 100.0
+            print('replay %d: sepconv 1 span %.1f us clock %.3f GHz wave life %.1f us | sepconv 2 span %.1f us clock %.3f GHz wave life %.1f us | '
+                  'end of 1 -> start of 2: %.1f us' % (rep, rows[0][0], rows[0][1], rows[0][2], rows[1][0], rows[1][1], rows[1][2], gap), flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -287,6 +287,7 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 17: return fwd_asm_three_channels(input, vertical, horizontal, output, B, C, H, W, s);
 #ifdef TAI_TIMING_VARIANTS   // timing experiments (wrong results by design): tools/ build only, never in the shipped library
         case 108: return fwd_ab_all_channels<3, 3>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 109: return fwd_ab_all_channels<4, 3>(input, vertical, horizontal, output, B, C, H, W, s);   // the default kernel (16) with stamps
         case 106: return fwd_ab_all_channels<0, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 107: return fwd_ab_all_channels<2, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 111: return fwd_asm_all_channels<false, 0, 8, 2>(input, vertical, horizontal, output, B, C, H, W, s);
