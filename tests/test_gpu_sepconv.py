@@ -62,7 +62,7 @@ def test_forward_and_backward_match_oracle(B, C, H, W, ks):
     assert _rel(out.detach().cpu().numpy(), lit.astype(np.float64)) < 2 * FWD_TOL
 
 
-@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize('C', [1, 3])
 def test_every_forward_variant(variant, C):
     inp, v, h, _ = _case(2, C, 24, 128, 51, 5)
@@ -72,6 +72,33 @@ def test_every_forward_variant(variant, C):
         with torch.no_grad():
             out = vfi.SeparableConvolution.apply(inp.to(DEV), v.to(DEV), h.to(DEV), 51)
         assert _rel(out.cpu().numpy(), ref) < FWD_TOL
+    finally:
+        sc.set_forward_variant(prev)
+
+
+@pytest.mark.parametrize('variant', [16, 18])
+@pytest.mark.parametrize('B,H,W', [(2, 40, 256), (1, 16, 132), (3, 16, 128), (1, 24, 4)])
+def test_mixed_wave_kernels_on_ragged_tiles_and_patch_edges(variant, B, H, W):
+    """The A/B kernels on several column tiles, a ragged last row tile and a narrow last column tile; delta taps at
+    (50, 50) read the LAST two columns and rows of the padded frame (kernel 18 stages those two columns separately)."""
+    ks = 51
+    inp, v, h, _ = _case(B, 1, H, W, ks, 17)
+    prev = sc.set_forward_variant(variant)
+    try:
+        with torch.no_grad():
+            out = vfi.SeparableConvolution.apply(inp.to(DEV), v.to(DEV), h.to(DEV), ks)
+            assert _rel(out.cpu().numpy(), so.forward(inp.numpy(), v.numpy(), h.numpy(), ks, f64=True)) < FWD_TOL
+            dv = torch.zeros_like(v); dv[:, 50] = 1
+            dh = torch.zeros_like(h); dh[:, 50] = 1
+            out = vfi.SeparableConvolution.apply(inp.to(DEV), dv.to(DEV), dh.to(DEV), ks).cpu()
+            assert torch.equal(out, inp[:, :, 50:50 + H, 50:50 + W])
+            # LDS keeps its contents from launch to launch: a patch element read before it was staged would be the PREVIOUS
+            # launch's value.  Alternate a frame with its negation (the exact negative, bit for bit): any stale read shows.
+            a, b2, dvv, dhh = inp.to(DEV), (-inp).to(DEV), v.to(DEV), h.to(DEV)
+            pos = vfi.SeparableConvolution.apply(a, dvv, dhh, ks)
+            for _ in range(10):
+                assert torch.equal(vfi.SeparableConvolution.apply(b2, dvv, dhh, ks), -pos)
+                assert torch.equal(vfi.SeparableConvolution.apply(a, dvv, dhh, ks), pos)
     finally:
         sc.set_forward_variant(prev)
 

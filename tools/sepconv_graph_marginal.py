@@ -28,6 +28,10 @@ def replay_ms(graph, n=6):
 
 
 def main():
+    from video_frame_inpainting_amd import separable_convolution as sc
+    if len(sys.argv) > 1:
+        sc.set_forward_variant(int(sys.argv[1]))
+        print('forward variant', sys.argv[1])
     g = torch.Generator().manual_seed(7)
     inp = (torch.rand(N, 1, H + KS - 1, W + KS - 1, generator=g) * 2 - 1).to(dev)
     v = torch.empty(N, KS, H, W, device=dev)

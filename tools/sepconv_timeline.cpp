@@ -7,7 +7,7 @@
 #include "tai_sepconv.h"
 int main(int argc, char** argv) {
     const int var = argc > 1 ? atoi(argv[1]) : 103, waves = (var == 105) ? 4 : 8;
-    const int RS = (var >= 106 && var <= 109) ? 8 : 5;      // 8-byte records per wave (the A/B kernels also stamp the shader clock)
+    const int RS = (var >= 106 && var <= 110) ? 8 : 5;      // 8-byte records per wave (the A/B kernels also stamp the shader clock)
     const int B = 32, C = 1, H = 128, W = 128, ks = 51, Hp = H + ks - 1, Wp = W + ks - 1;
     float *din, *dv, *dh, *dout;
     hipMalloc(&din, (size_t)B * Hp * Wp * 4); hipMalloc(&dv, (size_t)B * ks * H * W * 4); hipMalloc(&dh, (size_t)B * ks * H * W * 4); hipMalloc(&dout, (size_t)B * H * W * 4);

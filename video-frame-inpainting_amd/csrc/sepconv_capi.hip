@@ -129,7 +129,7 @@ int fwd_ab_all_channels(const float* in, const float* v, const float* h, float* 
     const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W;
     const int tiles_y = (H + 15) / 16;
     const size_t patch = (size_t)(16 + 50) * 180 * sizeof(float);
-    const size_t lds = ((patch + 1023) & ~(size_t)1023) + (size_t)8 * TAI_FWD_ROWLOOP_RING_SLOTS * 1024;
+    const size_t lds = ((patch + 1023) & ~(size_t)1023) + (size_t)8 * TAI_FWD_ROWLOOP_RING_SLOTS * 1024 + (MIXMODE == 5 ? 16 : 0);
     auto kern = fwd::sepconv_forward_ab<MIXMODE, DBG>;
     if (int rc = allow_lds(kern, lds)) return rc;
     for (int c0 = 0; c0 < C; ++c0) {
@@ -224,7 +224,7 @@ int launch_grad_vh_tiled(const float* gO, const float* in, const float* v, const
 
 extern "C" {
 
-int tai_sepconv_version(void) { return 300; }     // 0.3.0: + tai_conv3x3_wino_wrw*, tai_sn_power_iteration, shift_k
+int tai_sepconv_version(void) { return 310; }     // 0.3.1: forward kernel 18 (tap loads at entry) is the C == 1 default
 
 const char* tai_sepconv_last_error(void) { return g_err; }
 
@@ -236,7 +236,7 @@ int tai_sepconv_set_grad_input_variant(int variant) { return g_gi_variant.exchan
 
 int tai_sepconv_default_forward_variant(int C, int W, int ks) {
     const bool tileable = (ks == 51) && (W % 4 == 0);
-    return !tileable ? 1 : (C == 1 ? 16 : 17);
+    return !tileable ? 1 : (C == 1 ? 18 : 17);
 }
 
 long long tai_sepconv_forward_bytes(int B, int C, int H, int W, int ks) {
@@ -282,12 +282,14 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 12: return fwd_ab_all_channels<2>(input, vertical, horizontal, output, B, C, H, W, s);
         case 13: return fwd_ab_all_channels<3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 16: return fwd_ab_all_channels<4>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 18: return fwd_ab_all_channels<5>(input, vertical, horizontal, output, B, C, H, W, s);
         case 14: return fwd_asm_channel_loop<8>(input, vertical, horizontal, output, B, C, H, W, s);
         case 15: return fwd_asm_channel_loop<4>(input, vertical, horizontal, output, B, C, H, W, s);
         case 17: return fwd_asm_three_channels(input, vertical, horizontal, output, B, C, H, W, s);
 #ifdef TAI_TIMING_VARIANTS   // timing experiments (wrong results by design): tools/ build only, never in the shipped library
         case 108: return fwd_ab_all_channels<3, 3>(input, vertical, horizontal, output, B, C, H, W, s);
-        case 109: return fwd_ab_all_channels<4, 3>(input, vertical, horizontal, output, B, C, H, W, s);   // the default kernel (16) with stamps
+        case 109: return fwd_ab_all_channels<4, 3>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 16 with stamps
+        case 110: return fwd_ab_all_channels<5, 3>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 18 with stamps
         case 106: return fwd_ab_all_channels<0, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 107: return fwd_ab_all_channels<2, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 111: return fwd_asm_all_channels<false, 0, 8, 2>(input, vertical, horizontal, output, B, C, H, W, s);
