@@ -8,7 +8,9 @@ temporal reversal -- and the same ``{'targets': [T, C, H, W], 'clip_label': str}
 What differs is where frames come from.  The reference opens every path with ``imageio.get_reader(path, 'ffmpeg')``
 (:106-122); neither imageio nor cv2 exists in this image, so a "video" here is, in this order: a directory of image
 files (sorted by name; PNG / JPEG / BMP through PIL), a ``.npy`` file or an ``.npz`` member ``frames`` holding
-``[T, H, W, 3]`` uint8 RGB, and only then an imageio reader if imageio can be imported at run time.  The resize is a
+``[T, H, W, 3]`` uint8 RGB, then an imageio reader if imageio can be imported at run time, else video_io.py's own readers:
+AVI files with intra-frame codecs (uncompressed, Motion-JPEG, PNG) and PIL frame sequences (GIF, TIFF, APNG, WebP).
+Inter-frame codecs (DivX, H.264) are refused with the FourCC in the message.  The resize is a
 numpy restatement of OpenCV's INTER_LINEAR (half-pixel centres, edge clamp, no antialiasing) rounded to nearest; OpenCV
 computes it in 11-bit fixed point for uint8, so single pixels may differ from it by one grey level.
 """
@@ -69,7 +71,11 @@ def open_frame_source(path):
             return _ArrayVideo(np.load(path, mmap_mode='r'), path)
         if path.endswith('.npz'):
             return _ArrayVideo(np.load(path)['frames'], path)
-        import imageio                                              # absent in this image; used when present
+        try:
+            import imageio                                          # absent in this image; used when present
+        except ImportError:
+            from .video_io import open_video_file                   # AVI (uncompressed / Motion-JPEG / PNG), GIF, TIFF, ...
+            return open_video_file(path)
         return imageio.get_reader(path, 'ffmpeg')
     except (IOError, OSError, ImportError, KeyError, ValueError) as e:
         warn('Failed to open video %s: %s' % (path, e))
