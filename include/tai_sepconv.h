@@ -245,8 +245,9 @@ int tai_conv3x3_wino_timeline_skip(int level);
  *       eighth of the tile list, 18 (default for C == 1) = 16 with the type-A tap loads issued at kernel entry: the patch
  *       is staged by the type-B waves alone (LDS-DMA) and announced through an LDS counter instead of a workgroup barrier,
  *   14/15 = type-A waves that load their taps once and run the row loop once per channel (8- / 4-wave workgroups),
- *   17 (default for C > 1) = type-A waves that walk three channel patches per tap row: v and h are read once for all
- *       three channels (channels beyond a multiple of three run on the single-channel kernel).
+ *   17 = type-A waves that walk three channel patches per tap row: v and h are read once for all three channels
+ *       (channels beyond a multiple of three run on the single-channel kernel), 19 (default for C > 1) = 17 with the three
+ *       patches staged by LDS-DMA and the tap loads issued right behind them (patch and h stream travel together).
  *   Values >= 100 (timing experiments that produce wrong results) exist only in the tools build of the library
  *   (-DTAI_TIMING_VARIANTS, build/libtai_sepconv_timing.so); the shipped library rejects them with TAI_SEPCONV_EINVAL.
  * Returns the previous value. */
@@ -266,7 +267,9 @@ int tai_sepconv_default_forward_variant(int C, int W, int ks);
 int tai_sepconv_set_grad_input_variant(int variant);
 
 /* grad_vertical / grad_horizontal kernels: 0 = automatic (one fused launch of the hand-scheduled wave types when C == 1
- * and both are requested), 1 = the two separate HIP kernels.  Returns the previous value. */
+ * and both are requested; the gV waves' tap loads issued at kernel entry, the patch staged by the gH waves through LDS-DMA),
+ * 1 = the two separate HIP kernels, 2 = the fused launch with the patch staged behind a workgroup barrier first (round 2's
+ * form, A/B).  Returns the previous value. */
 int tai_sepconv_set_grad_taps_variant(int variant);
 
 /* Algorithmic HBM bytes of one call: each operand read once, each result written once. */

@@ -62,7 +62,7 @@ def test_forward_and_backward_match_oracle(B, C, H, W, ks):
     assert _rel(out.detach().cpu().numpy(), lit.astype(np.float64)) < 2 * FWD_TOL
 
 
-@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19])
 @pytest.mark.parametrize('C', [1, 3])
 def test_every_forward_variant(variant, C):
     inp, v, h, _ = _case(2, C, 24, 128, 51, 5)
@@ -212,7 +212,7 @@ def test_fused_and_separate_tap_gradient_kernels_agree():
     inp, v, h, gO = _case(2, 1, 24, 128, 51, 13)
     _, rV, rH = so.backward(gO.numpy(), inp.numpy(), v.numpy(), h.numpy(), 51, f64=True)
     L = _native.lib()
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         prev = L.tai_sepconv_set_grad_taps_variant(variant)
         try:
             dv, dh = v.to(DEV).requires_grad_(), h.to(DEV).requires_grad_()

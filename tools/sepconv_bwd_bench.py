@@ -42,8 +42,11 @@ def timed(gi, gv, gh, per_graph=20, replays=5):
     return e0.elapsed_time(e1) * 1e3 / (per_graph * replays)
 
 
-taps = timed(None, gV, gH)
-print('[%d,%d,%d,%d] tap gradients (gV + gH): %.1f us' % (B, C, H, W, taps))
+for tv, name in ((2, 'patch staged behind a barrier, then the tap loads (round 2)'), (0, 'tap loads at entry, patch by LDS-DMA (default)'), (2, 'again'), (0, 'again')):
+    prev = L.tai_sepconv_set_grad_taps_variant(tv)
+    taps = timed(None, gV, gH)
+    L.tai_sepconv_set_grad_taps_variant(prev)
+    print('[%d,%d,%d,%d] tap gradients (gV + gH), variant %d (%s): %.1f us' % (B, C, H, W, tv, name, taps))
 for variant, name in ((0, 'strips, assembly row loop + slab sum (default)'), (4, 'strips, HIP C++ row loop + slab sum'), (2, 'round-1 row scatter + atomics'), (1, 'gather')):
     if variant == 1 and B * C * H * W > 2 ** 19:
         continue

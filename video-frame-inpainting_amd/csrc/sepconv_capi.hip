@@ -154,10 +154,11 @@ int fwd_asm_channel_loop(const float* in, const float* v, const float* h, float*
 }
 
 // channels in groups of three through the three-patch row loop; what is left over through the per-channel loop
+template <bool EARLY>
 int fwd_asm_three_channels(const float* in, const float* v, const float* h, float* out, int B, int C, int H, int W, hipStream_t s) {
     const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W, tiles_y = (H + 15) / 16;
     const size_t lds = (size_t)3 * TAI_FWD_ROWLOOP_C3_PATCH_BYTES + (size_t)8 * TAI_FWD_ROWLOOP_C3_RING_SLOTS * 1024;
-    auto kern = fwd::sepconv_forward_asm_c3;
+    auto kern = fwd::sepconv_forward_asm_c3<EARLY>;
     if (int rc = allow_lds(kern, lds)) return rc;
     int c0 = 0;
     for (; c0 + 3 <= C; c0 += 3) {
@@ -167,7 +168,7 @@ int fwd_asm_three_channels(const float* in, const float* v, const float* h, floa
     for (; c0 < C; ++c0) {
         const size_t patch = (size_t)(16 + 50) * 180 * sizeof(float);
         const size_t lds1 = ((patch + 1023) & ~(size_t)1023) + (size_t)8 * TAI_FWD_ROWLOOP_RING_SLOTS * 1024;
-        auto k1 = fwd::sepconv_forward_ab<4, 0>;
+        auto k1 = fwd::sepconv_forward_ab<4, 0>;       // (kernel 16: its LDS size has no counter word)
         if (int rc = allow_lds(k1, lds1)) return rc;
         hipLaunchKernelGGL(k1, dim3(B * tiles_x * tiles_y), dim3(512), lds1, s, in, v, h, out, C, c0, H, W, tiles_x, tiles_y);
         if (int rc = check_launch("sepconv_forward_ab")) return rc;
@@ -236,7 +237,7 @@ int tai_sepconv_set_grad_input_variant(int variant) { return g_gi_variant.exchan
 
 int tai_sepconv_default_forward_variant(int C, int W, int ks) {
     const bool tileable = (ks == 51) && (W % 4 == 0);
-    return !tileable ? 1 : (C == 1 ? 18 : 17);
+    return !tileable ? 1 : (C == 1 ? 18 : 19);
 }
 
 long long tai_sepconv_forward_bytes(int B, int C, int H, int W, int ks) {
@@ -285,7 +286,8 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 18: return fwd_ab_all_channels<5>(input, vertical, horizontal, output, B, C, H, W, s);
         case 14: return fwd_asm_channel_loop<8>(input, vertical, horizontal, output, B, C, H, W, s);
         case 15: return fwd_asm_channel_loop<4>(input, vertical, horizontal, output, B, C, H, W, s);
-        case 17: return fwd_asm_three_channels(input, vertical, horizontal, output, B, C, H, W, s);
+        case 17: return fwd_asm_three_channels<false>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 19: return fwd_asm_three_channels<true>(input, vertical, horizontal, output, B, C, H, W, s);
 #ifdef TAI_TIMING_VARIANTS   // timing experiments (wrong results by design): tools/ build only, never in the shipped library
         case 108: return fwd_ab_all_channels<3, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 109: return fwd_ab_all_channels<4, 3>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 16 with stamps
@@ -907,10 +909,18 @@ int tai_sepconv_backward(const float* grad_output, const float* input, const flo
         const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W, tiles_y = (H + 7) / 8;
         const size_t patch = (size_t)(8 + 50) * 180 * sizeof(float);
         const size_t lds = ((patch + 1023) & ~(size_t)1023) + (size_t)8 * TAI_FWD_ROWLOOP_RING_SLOTS * 1024;
-        auto kern = bwd::sepconv_grad_vh_ab;
-        if (int rc = allow_lds(kern, lds)) return rc;
-        hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(512), lds, s, grad_output, input, vertical, horizontal,
-                           grad_vertical, grad_horizontal, H, W, tiles_x, tiles_y);
+        // (variant 2: the round-2 form that stages the patch behind a workgroup barrier before the tap loads; A/B and tests)
+        if (g_vh_variant.load(std::memory_order_relaxed) == 2) {
+            auto kern = bwd::sepconv_grad_vh_ab<false>;
+            if (int rc = allow_lds(kern, lds)) return rc;
+            hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(512), lds, s, grad_output, input, vertical, horizontal,
+                               grad_vertical, grad_horizontal, H, W, tiles_x, tiles_y);
+        } else {
+            auto kern = bwd::sepconv_grad_vh_ab<true>;
+            if (int rc = allow_lds(kern, lds)) return rc;
+            hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(512), lds, s, grad_output, input, vertical, horizontal,
+                               grad_vertical, grad_horizontal, H, W, tiles_x, tiles_y);
+        }
         if (int rc = check_launch("sepconv_grad_vh_ab")) return rc;
     } else if (tileable) {
         const int rc = (C == 1) ? launch_grad_vh_tiled<51, 1>(grad_output, input, vertical, horizontal,
