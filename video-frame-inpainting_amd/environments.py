@@ -212,6 +212,13 @@ class BaseTrainingEnvironment(BaseVideoFillInEnvironment):
             # ends in a fault inside the HIP runtime when the capture is closed (tools/graph_op_bisect.py gen_keep_out*,
             # tools/graph_step_bisect.py m0).
             self._detach_step_outputs()
+            # ... and whatever autograd graph pieces are only kept alive by reference cycles go NOW, not at some allocation
+            # inside the capture.  What this cannot see is a caller that still holds a tensor with history from an earlier eager
+            # update (a loss, ``env.gen_output['pred']``): the capturing call is made with such references dropped or detached.
+            import gc
+            gc.collect()
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('train_step: already inside a stream capture; a step graph cannot be nested')
             with torch.cuda.graph(graph):
                 self.forward_train()
                 self.optimize_parameters()
