@@ -242,8 +242,11 @@ int tai_conv3x3_wino_timeline_skip(int level);
  *       the tap loads of half the waves deferred behind a workgroup barrier, 7-9 = 16-row tiles (8 waves),
  *   10-13 = 8-wave workgroups mixing "taps first" (type A) and "taps last" (type B) waves on every SIMD;
  *       13 adds 16-byte patch staging and alternating wave priorities, 16 = 13 with each XCD given a contiguous
- *       eighth of the tile list, 18 (default for C == 1) = 16 with the type-A tap loads issued at kernel entry: the patch
- *       is staged by the type-B waves alone (LDS-DMA) and announced through an LDS counter instead of a workgroup barrier,
+ *       eighth of the tile list, 18 = 16 with the type-A tap loads issued at kernel entry: the patch is staged by the
+ *       type-B waves alone (LDS-DMA) and announced through an LDS counter instead of a workgroup barrier,
+ *   20 (default for C == 1) = kernel 18's wave types as ONE persistent workgroup per CU when the launch has more tiles than
+ *       the device has CUs (and a multiple of 8 of them): the next tile's patch and taps are on their way while this tile
+ *       computes; with at most one tile per CU it IS kernel 18 (selected explicitly, 20 runs persistent at any tile count),
  *   14/15 = type-A waves that load their taps once and run the row loop once per channel (8- / 4-wave workgroups),
  *   17 = type-A waves that walk three channel patches per tap row: v and h are read once for all three channels
  *       (channels beyond a multiple of three run on the single-channel kernel), 19 (default for C > 1) = 17 with the three

@@ -62,7 +62,7 @@ def test_forward_and_backward_match_oracle(B, C, H, W, ks):
     assert _rel(out.detach().cpu().numpy(), lit.astype(np.float64)) < 2 * FWD_TOL
 
 
-@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20])
 @pytest.mark.parametrize('C', [1, 3])
 def test_every_forward_variant(variant, C):
     inp, v, h, _ = _case(2, C, 24, 128, 51, 5)
@@ -76,7 +76,7 @@ def test_every_forward_variant(variant, C):
         sc.set_forward_variant(prev)
 
 
-@pytest.mark.parametrize('variant', [16, 18])
+@pytest.mark.parametrize('variant', [16, 18, 20])
 @pytest.mark.parametrize('B,H,W', [(2, 40, 256), (1, 16, 132), (3, 16, 128), (1, 24, 4)])
 def test_mixed_wave_kernels_on_ragged_tiles_and_patch_edges(variant, B, H, W):
     """The A/B kernels on several column tiles, a ragged last row tile and a narrow last column tile; delta taps at
@@ -101,6 +101,36 @@ def test_mixed_wave_kernels_on_ragged_tiles_and_patch_edges(variant, B, H, W):
                 assert torch.equal(vfi.SeparableConvolution.apply(a, dvv, dhh, ks), pos)
     finally:
         sc.set_forward_variant(prev)
+
+
+@pytest.mark.parametrize('B', [16, 40, 72])
+def test_persistent_forward_kernel_matches_the_one_tile_kernels_bit_for_bit(B):
+    """Kernel 20 (one persistent workgroup per CU, the next tile's patch and taps on their way while this tile computes) runs
+    the same row loops as kernels 16 / 18: identical bits.  B = 16: fewer tiles than CUs (every workgroup one tile); B = 40, 72:
+    320 / 576 tiles on 256 workgroups -- one to three rounds per workgroup, both patch buffers reused.  Plus an oracle slice, and
+    the alternation with the exact negation (a stale patch or tap read would show)."""
+    ks, H, W = 51, 128, 128
+    g = torch.Generator().manual_seed(B)
+    inp = (torch.rand(B, 1, H + ks - 1, W + ks - 1, generator=g) * 2 - 1).to(DEV)
+    v = (torch.randn(B, ks, H, W, generator=g) * 0.1).to(DEV)
+    h = (torch.randn(B, ks, H, W, generator=g) * 0.1).to(DEV)
+    outs = {}
+    with torch.no_grad():
+        for variant in (16, 18, 20):
+            prev = sc.set_forward_variant(variant)
+            try:
+                outs[variant] = vfi.SeparableConvolution.apply(inp, v, h, ks)
+                if variant == 20:
+                    neg = -inp
+                    for _ in range(4):
+                        assert torch.equal(vfi.SeparableConvolution.apply(neg, v, h, ks), -outs[20])
+                        assert torch.equal(vfi.SeparableConvolution.apply(inp, v, h, ks), outs[20])
+            finally:
+                sc.set_forward_variant(prev)
+    assert torch.equal(outs[20], outs[16]) and torch.equal(outs[20], outs[18])
+    sl = slice(B - 2, B)
+    ref = so.forward(inp[sl].cpu().numpy(), v[sl].cpu().numpy(), h[sl].cpu().numpy(), ks, f64=True)
+    assert _rel(outs[20][sl].cpu().numpy(), ref) < FWD_TOL
 
 
 @pytest.mark.parametrize('i,j', [(0, 0), (50, 50), (25, 3), (1, 48), (49, 2)])

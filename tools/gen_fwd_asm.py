@@ -327,6 +327,41 @@ def emit_row_gv(L, phase):
     L.append('s_add_u32 %s, %s, 1' % (S_ROW, S_ROW))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# type-B epilogue of the persistent forward kernel: out_p = sum_t h_p[t] * c_p[t] with the accumulators c in v[0:203] (the
+# row loop's outputs, tap t of pixel p in v[51 p + t]) and h streamed once, 16 bytes per lane per tap, ELEVEN loads in flight
+# (v[204:239] and v[244:251]; the HIP C++ form of this fold, compiled inside the tile loop, was left with one free register quad and waited
+# for every load before issuing the next).  s[60:61] = &h[b, 0, 0, 0], s62 = plane bytes, v242 = the lane's byte offset in the
+# plane; result in v[252:255].
+FOLD_BASES = [204 + 4 * k for k in range(9)] + [244, 248]     # eleven register quads (tuples start on even registers); v240-v242 are inputs and stay intact
+FOLD_BUFS = len(FOLD_BASES)
+
+
+def gen_fold():
+    L = []
+    L.append('s_mov_b32 %s, s60' % S_PTR_LO)
+    L.append('s_mov_b32 %s, s61' % S_PTR_HI)
+    for p in range(4):
+        L.append('v_mov_b32 v%d, 0' % (252 + p))
+
+    def issue(t):
+        base = FOLD_BASES[t % FOLD_BUFS]
+        L.append('global_load_dwordx4 v[%d:%d], v%d, s[64:65]' % (base, base + 3, V_GOFF))
+        L.append('s_add_u32 %s, %s, %s' % (S_PTR_LO, S_PTR_LO, S_PLANE))
+        L.append('s_addc_u32 %s, %s, 0' % (S_PTR_HI, S_PTR_HI))
+    for t in range(FOLD_BUFS):
+        issue(t)
+    for t in range(KS):
+        # loads t .. min(t + FOLD_BUFS, KS) - 1 are outstanding; load t is the oldest
+        L.append('s_waitcnt vmcnt(%d)' % (min(t + FOLD_BUFS, KS) - 1 - t))
+        base = FOLD_BASES[t % FOLD_BUFS]
+        for p in range(4):
+            L.append('v_fmac_f32 v%d, v%d, v%d' % (252 + p, base + p, KS * p + t))
+        if t + FOLD_BUFS < KS:
+            issue(t + FOLD_BUFS)
+    return L
+
+
 def gen_gv():
     L = []
     L.append('v_mov_b32 v%d, v%d' % (V_ROW, V_ROW_IN))
@@ -645,6 +680,14 @@ def main():
         for l in lines:
             f.write('    "%s\\n" \\\n' % l)
         f.write('    ""\n')
+        lines = gen_fold()
+        f.write('// TAI_FWD_FOLD_ASM (type-B tap fold of the persistent kernel, %d loads in flight): %d instructions.\n' % (FOLD_BUFS, len(lines)))
+        f.write('#define TAI_FWD_FOLD_ASM \\\n')
+        for l in lines:
+            f.write('    "%s\\n" \\\n' % l)
+        f.write('    ""\n')
+        clob_fold = ['v%d' % r for b in FOLD_BASES for r in range(b, b + 4)] + ['s64', 's65', 'scc', 'memory']
+        f.write('#define TAI_FWD_FOLD_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob_fold))
         lines = gen_c3()
         n_pk = sum(1 for l in lines if l.startswith('v_pk_'))
         f.write('// TAI_FWD_ROWLOOP_C3_ASM (three channel patches per tap row, v read once): %d instructions, %d packed.\n' % (len(lines), n_pk))

@@ -140,6 +140,38 @@ int fwd_ab_all_channels(const float* in, const float* v, const float* h, float* 
     return TAI_SEPCONV_OK;
 }
 
+// compute units of the current device (cached per device and thread, like allow_lds: no runtime call on the launch path after
+// the first)
+static int device_cu_count() {
+    static thread_local int cached_device = -1, cached_cus = 0;
+    int device = -1;
+    if (hipGetDevice(&device) != hipSuccess) return 0;
+    if (device != cached_device) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+        cached_device = device; cached_cus = n;
+    }
+    return cached_cus;
+}
+
+// kernel 20: one persistent workgroup per CU over the tiles of a single-channel frame batch; falls back to kernel 18 when there
+// is at most one tile per CU (nothing to overlap) or the tile count is not a multiple of 8 (the XCD-contiguous tile order)
+int fwd_persistent(const float* in, const float* v, const float* h, float* out, int B, int C, int H, int W, hipStream_t s, bool force) {
+    const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W, tiles_y = (H + 15) / 16;
+    const int ntiles = B * tiles_x * tiles_y;
+    const int cus = device_cu_count();
+    int grid = cus > 0 ? (cus / 8) * 8 : 0;
+    if (C != 1 || grid < 8 || ntiles % 8 != 0 || (!force && ntiles <= grid) || (long long)B * 51 * H * W * 4 > 0xffffffffLL)
+        return fwd_ab_all_channels<5>(in, v, h, out, B, C, H, W, s);
+    if (grid > ntiles) grid = ntiles;
+    const size_t patch = ((size_t)(16 + 50) * 180 * sizeof(float) + 1023) & ~(size_t)1023;
+    const size_t lds = 2 * patch + (size_t)8 * TAI_FWD_ROWLOOP_RING_SLOTS * 1024 + 16;
+    auto kern = fwd::sepconv_forward_persistent;
+    if (int rc = allow_lds(kern, lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, in, v, h, out, H, W, tiles_x, tiles_y, ntiles);
+    return check_launch("sepconv_forward_persistent");
+}
+
 template <int WAVES>
 int fwd_asm_channel_loop(const float* in, const float* v, const float* h, float* out, int B, int C, int H, int W,
                           hipStream_t s) {
@@ -225,7 +257,7 @@ int launch_grad_vh_tiled(const float* gO, const float* in, const float* v, const
 
 extern "C" {
 
-int tai_sepconv_version(void) { return 310; }     // 0.3.1: forward kernel 18 (tap loads at entry) is the C == 1 default
+int tai_sepconv_version(void) { return 320; }     // 0.3.2: forward kernels 18 / 20 (persistent where tiles > CUs) for C == 1, 19 for C > 1
 
 const char* tai_sepconv_last_error(void) { return g_err; }
 
@@ -237,7 +269,7 @@ int tai_sepconv_set_grad_input_variant(int variant) { return g_gi_variant.exchan
 
 int tai_sepconv_default_forward_variant(int C, int W, int ks) {
     const bool tileable = (ks == 51) && (W % 4 == 0);
-    return !tileable ? 1 : (C == 1 ? 18 : 19);
+    return !tileable ? 1 : (C == 1 ? 20 : 19);
 }
 
 long long tai_sepconv_forward_bytes(int B, int C, int H, int W, int ks) {
@@ -288,6 +320,7 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 15: return fwd_asm_channel_loop<4>(input, vertical, horizontal, output, B, C, H, W, s);
         case 17: return fwd_asm_three_channels<false>(input, vertical, horizontal, output, B, C, H, W, s);
         case 19: return fwd_asm_three_channels<true>(input, vertical, horizontal, output, B, C, H, W, s);
+        case 20: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, g_fwd_variant.load(std::memory_order_relaxed) == 20);
 #ifdef TAI_TIMING_VARIANTS   // timing experiments (wrong results by design): tools/ build only, never in the shipped library
         case 108: return fwd_ab_all_channels<3, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 109: return fwd_ab_all_channels<4, 3>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 16 with stamps
