@@ -11,8 +11,14 @@ def short(name):
     return name.split('(')[0][:110]
 
 
+def newest(pattern):
+    """Only the newest matching file: gpurun merges a re-run's output into the same directory under a new process id."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
 def stats_rows(sub):
-    for p in glob.glob('%s/%s/*/*_kernel_stats.csv' % (root, sub)):
+    for p in newest('%s/%s/*/*_kernel_stats.csv' % (root, sub)):
         rows = list(csv.DictReader(open(p)))
         rows.sort(key=lambda r: -float(r['TotalDurationNs']))
         return rows
@@ -20,7 +26,7 @@ def stats_rows(sub):
 
 
 def trace_rows(sub):
-    for p in glob.glob('%s/%s/*/*_kernel_trace.csv' % (root, sub)):
+    for p in newest('%s/%s/*/*_kernel_trace.csv' % (root, sub)):
         return list(csv.DictReader(open(p)))
     return []
 
@@ -28,7 +34,7 @@ def trace_rows(sub):
 def counters(sub, match):
     """{(kernel, grid): {counter: [values]}}, plus per-dispatch durations under '_us', over dispatches whose name contains `match`."""
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for p in glob.glob('%s/%s/*/*_counter_collection.csv' % (root, sub)):
+    for p in newest('%s/%s/*/*_counter_collection.csv' % (root, sub)):
         seen = set()
         for r in csv.DictReader(open(p)):
             if match in r['Kernel_Name']:
@@ -51,33 +57,43 @@ with open(os.path.join(res_dir, 'r03_bench_kernel_stats_top40.csv'), 'w') as f:
         w.writerow([r['Name'][:160], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
 
 # ---- sepconv forward by grid: trace durations and counters for BOTH launch shapes
+def launch_class(kernel, grid):
+    """131072 = the [32,1,128,128] roofline launch; 655360 = the in-model launch [160,1,128,128] -- one-tile kernels have that grid,
+    the persistent kernel (one workgroup per CU: grid 131072 as well) is told by its name."""
+    if 'persistent' in kernel:
+        return 655360
+    return grid
+
+
 by_grid = collections.defaultdict(list)
 for r in trace_rows('bench_trace'):
     if 'sepconv_forward' in r['Kernel_Name']:
-        by_grid[(short(r['Kernel_Name']), int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0))].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+        k = short(r['Kernel_Name'])
+        by_grid[(k, launch_class(k, int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0)))].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 ALG = {131072: 220062208, 655360: 1100311040}
 lines = ['rocprofv3 of `%s` (r03), sepconv forward launches by grid size' % CMD,
-         '(grid 131072 threads = 256 workgroups x 512 = the [32,1,128,128] roofline shape, re-read by back-to-back graph replays: Infinity-Cache-warm;',
-         ' grid 655360 = the in-model launch over all 5 time steps, [160,1,128,128], its 1.07 GB of taps just written by the preceding convolutions)',
+         '([32,1,128,128] = the roofline shape, 256 one-tile workgroups, re-read by back-to-back graph replays: Infinity-Cache-warm;',
+         ' [160,1,128,128] = the in-model launch over all 5 time steps, its 1.07 GB of taps just written by the preceding convolutions; kernel 20: 256 persistent workgroups)',
          '', '-- kernel trace (--kernel-trace --stats run)']
 fwd_avg = {}
 for (k, g), v in sorted(by_grid.items()):
     v = sorted(v)
     m = mean(v)
     frac = ALG.get(g, 0) / (m * 1e-6) / 8e12 if g in ALG else float('nan')
-    lines.append('%s grid %d: %d launches, mean %.2f us, median %.2f us, min %.2f us  -> %.3f of 8 TB/s by the mean (%.3f by the median)' % (
-        k, g, len(v), m, v[len(v) // 2], v[0], frac, ALG.get(g, 0) / (v[len(v) // 2] * 1e-6) / 8e12 if g in ALG else float('nan')))
+    lines.append('%s %s: %d launches, mean %.2f us, median %.2f us, min %.2f us  -> %.3f of 8 TB/s by the mean (%.3f by the median)' % (
+        k, {131072: '[32,1,128,128]', 655360: '[160,1,128,128] (in-model)'}.get(g, 'grid %d' % g), len(v), m, v[len(v) // 2], v[0], frac,
+        ALG.get(g, 0) / (v[len(v) // 2] * 1e-6) / 8e12 if g in ALG else float('nan')))
     fwd_avg[g] = {'launches': len(v), 'mean_us': m, 'median_us': v[len(v) // 2], 'min_us': v[0], 'kernel': k}
 lines += ['', '-- counters (separate --pmc passes of the same command; per-dispatch means)']
 per_grid = collections.defaultdict(dict)
 for sub in ('bench_fetch', 'bench_write', 'bench_sq', 'bench_lds'):
     for (k, g), d in counters(sub, 'sepconv_forward').items():
         for c, v in d.items():
-            per_grid[g][(sub, c)] = mean(v)
+            per_grid[launch_class(k, g)][(sub, c)] = mean(v)
 for g in sorted(per_grid):
     d = per_grid[g]
     fetch, write = d.get(('bench_fetch', 'FETCH_SIZE')), d.get(('bench_write', 'WRITE_SIZE'))
-    lines.append('grid %d:' % g)
+    lines.append('%s:' % {131072: '[32,1,128,128] (grid 131072, fwd::sepconv_forward_ab<5, 0>)', 655360: '[160,1,128,128] in-model (fwd::sepconv_forward_persistent, 256 workgroups)'}.get(g, 'grid %d' % g))
     if fetch is not None and write is not None:
         hbm = 2 * fetch * 1024 + write * 1024
         lines.append('  FETCH_SIZE %.0f KB (x2: gfx950 half-count for 16 B/lane reads) + WRITE_SIZE %.0f KB = %.1f MB per launch = %.4f x the algorithmic %d B' % (
