@@ -124,6 +124,26 @@ def sepconv_roofline(device, B, iters=200, warmup=20):
             'in_model': sepconv_in_model_roofline(device, B)}
 
 
+def hbm_streaming_copy(device, reps=10):
+    """What this box's memory system sustains for a plain streaming kernel: a 1 GiB -> 1 GiB copy, read + written bytes over the
+    time between HIP events.  The boxes of the pool differ (4.9-5.2 TB/s seen), and the in-model sepconv launch -- five rounds of
+    816 KB per CU, 43 us each: tools/sepconv_persistent_timeline.py -- runs at this rate, not at the 8 TB/s spec."""
+    a = torch.empty(256 << 20, dtype=torch.float32, device=device).normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record(); e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    del a, b
+    torch.cuda.empty_cache()
+    return 2.0 * (256 << 20) * 4 / us / 1e3       # GB/s
+
+
 def sepconv_in_model_roofline(device, B, reps=10):
     """The launch the model makes: all T time steps in one, [T*B,1,128,128] (grid 655360 at B = 32), its 2 x 534 MB of tap
     planes just written by the kernel network's last 51 -> 51 convolutions (4x the Infinity Cache: they come from HBM).
@@ -152,8 +172,13 @@ def sepconv_in_model_roofline(device, B, reps=10):
     us = float(np.mean(ts))
     nbytes = sc.forward_bytes(N, C_, H_, W_, ks)
     log('sepconv forward, in-model launch [%d,1,128,128] behind its tap-producing convolutions: mean %.1f us (min %.1f, max %.1f)' % (N, us, ts[0], ts[-1]))
+    del inp, x, w, b, v, h
+    torch.cuda.empty_cache()
+    copy_gbs = hbm_streaming_copy(device)
+    log('this box streams %.0f GB/s in a 1 GiB copy' % copy_gbs)
     return {'shape': [N, C_, H_, W_], 'us_per_launch': round(us, 1), 'us_min': round(ts[0], 1), 'us_max': round(ts[-1], 1),
             'achieved': round(nbytes / us / 1e3, 1), 'frac': round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4), 'algorithmic_bytes': nbytes,
+            'box_streaming_copy_GBps': round(copy_gbs, 1), 'frac_of_box_streaming_copy': round(nbytes / us / 1e3 / copy_gbs, 4),
             'inputs': 'HBM: %.0f MB of tap planes written by the two preceding convolutions, 4x the Infinity Cache' % (2 * N * ks * H_ * W_ * 4 / 1e6),
             'timing': 'HIP events around the launch, %d repetitions, mean (event overhead ~5 us included)' % reps}
 

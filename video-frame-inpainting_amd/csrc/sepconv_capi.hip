@@ -156,6 +156,7 @@ static int device_cu_count() {
 
 // kernel 20: one persistent workgroup per CU over the tiles of a single-channel frame batch; falls back to kernel 18 when there
 // is at most one tile per CU (nothing to overlap) or the tile count is not a multiple of 8 (the XCD-contiguous tile order)
+template <int DBG = 0>
 int fwd_persistent(const float* in, const float* v, const float* h, float* out, int B, int C, int H, int W, hipStream_t s, bool force) {
     const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W, tiles_y = (H + 15) / 16;
     const int ntiles = B * tiles_x * tiles_y;
@@ -166,7 +167,7 @@ int fwd_persistent(const float* in, const float* v, const float* h, float* out, 
     if (grid > ntiles) grid = ntiles;
     const size_t patch = ((size_t)(16 + 50) * 180 * sizeof(float) + 1023) & ~(size_t)1023;
     const size_t lds = 2 * patch + (size_t)8 * TAI_FWD_ROWLOOP_RING_SLOTS * 1024 + 16;
-    auto kern = fwd::sepconv_forward_persistent;
+    auto kern = fwd::sepconv_forward_persistent<DBG>;
     if (int rc = allow_lds(kern, lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, in, v, h, out, H, W, tiles_x, tiles_y, ntiles);
     return check_launch("sepconv_forward_persistent");
@@ -325,6 +326,7 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 108: return fwd_ab_all_channels<3, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 109: return fwd_ab_all_channels<4, 3>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 16 with stamps
         case 110: return fwd_ab_all_channels<5, 3>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 18 with stamps
+        case 120: return fwd_persistent<1>(input, vertical, horizontal, output, B, C, H, W, s, true);    // kernel 20 with stamps
         case 106: return fwd_ab_all_channels<0, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 107: return fwd_ab_all_channels<2, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 111: return fwd_asm_all_channels<false, 0, 8, 2>(input, vertical, horizontal, output, B, C, H, W, s);
