@@ -127,7 +127,7 @@ def sepconv_roofline(device, B, iters=200, warmup=20):
 def hbm_streaming_copy(device, reps=10):
     """What this box's memory system sustains for a plain streaming kernel: a 1 GiB -> 1 GiB copy, read + written bytes over the
     time between HIP events.  The boxes of the pool differ (4.9-5.2 TB/s seen), and the in-model sepconv launch -- five rounds of
-    816 KB per CU, 43 us each: tools/sepconv_persistent_timeline.py -- runs at this rate, not at the 8 TB/s spec."""
+    863 KB per CU, 43 us each: tools/sepconv_persistent_timeline.py -- runs at this rate, not at the 8 TB/s spec."""
     a = torch.empty(256 << 20, dtype=torch.float32, device=device).normal_()
     b = torch.empty_like(a)
     for _ in range(3):
@@ -145,11 +145,12 @@ def hbm_streaming_copy(device, reps=10):
 
 
 def sepconv_in_model_roofline(device, B, reps=10):
-    """The launch the model makes: all T time steps in one, [T*B,1,128,128] (grid 655360 at B = 32), its 2 x 534 MB of tap
+    """The launch the model makes: all T time steps in one, [T*B,1,128,128] (1,280 tiles at B = 32: kernel 20's 256 persistent
+    workgroups), its 2 x 534 MB of tap
     planes just written by the kernel network's last 51 -> 51 convolutions (4x the Infinity Cache: they come from HBM).
     Timed as in the model's stream order -- the two producing Winograd convolutions, then the sepconv -- with HIP events
     around the sepconv alone, kernels queued back to back.  profiles/ holds rocprofv3's duration of the same launch
-    inside the replayed forward (grid 655360) and the in-kernel span / shader clock from the tools build."""
+    inside the replayed forward and the in-kernel stamps from the tools build."""
     ks, N = 51, T_ * B
     g = torch.Generator().manual_seed(8)
     inp = (torch.rand(N, C_, H_ + ks - 1, W_ + ks - 1, generator=g) * 2 - 1).to(device)
