@@ -103,6 +103,30 @@ def test_mixed_wave_kernels_on_ragged_tiles_and_patch_edges(variant, B, H, W):
         sc.set_forward_variant(prev)
 
 
+@pytest.mark.parametrize('B,H,W', [(34, 128, 128), (48, 64, 256), (40, 40, 128), (24, 24, 384), (8, 16, 128), (65, 128, 128), (3, 128, 128)])
+def test_persistent_forward_kernel_shape_sweep(B, H, W):
+    """Kernel 20 over tile grids that are ragged in rows (H = 40, 24: clamped rows in the last tile), several column tiles wide
+    (W = 256, 384: only the last column tile has the two-float row tail), one round with idle workgroups, and counts the persistent
+    form does not take (tiles % 8 != 0: falls back to kernel 18) -- always the same bits as kernel 16, stale-LDS alternation included."""
+    ks = 51
+    g = torch.Generator().manual_seed(B * H + W)
+    inp = (torch.rand(B, 1, H + ks - 1, W + ks - 1, generator=g) * 2 - 1).to(DEV)
+    v = (torch.randn(B, ks, H, W, generator=g) * 0.1).to(DEV)
+    h = (torch.randn(B, ks, H, W, generator=g) * 0.1).to(DEV)
+    with torch.no_grad():
+        prev = sc.set_forward_variant(16)
+        try:
+            want = vfi.SeparableConvolution.apply(inp, v, h, ks)
+            sc.set_forward_variant(20)
+            for _ in range(3):
+                assert torch.equal(vfi.SeparableConvolution.apply(inp, v, h, ks), want)
+                assert torch.equal(vfi.SeparableConvolution.apply(-inp, v, h, ks), -want)
+            sc.set_forward_variant(0)           # the default route (persistent only with more tiles than CUs)
+            assert torch.equal(vfi.SeparableConvolution.apply(inp, v, h, ks), want)
+        finally:
+            sc.set_forward_variant(prev)
+
+
 @pytest.mark.parametrize('B', [16, 40, 72])
 def test_persistent_forward_kernel_matches_the_one_tile_kernels_bit_for_bit(B):
     """Kernel 20 (one persistent workgroup per CU, the next tile's patch and taps on their way while this tile computes) runs
