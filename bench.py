@@ -180,7 +180,8 @@ def sepconv_in_model_roofline(device, B, reps=10):
     return {'shape': [N, C_, H_, W_], 'us_per_launch': round(us, 1), 'us_min': round(ts[0], 1), 'us_max': round(ts[-1], 1),
             'achieved': round(nbytes / us / 1e3, 1), 'frac': round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4), 'algorithmic_bytes': nbytes,
             'box_streaming_copy_GBps': round(copy_gbs, 1), 'frac_of_box_streaming_copy': round(nbytes / us / 1e3 / copy_gbs, 4),
-            'inputs': 'HBM: %.0f MB of tap planes written by the two preceding convolutions, 4x the Infinity Cache' % (2 * N * ks * H_ * W_ * 4 / 1e6),
+            'inputs': 'HBM: %.0f MB of tap planes written by the two preceding convolutions, %.1fx the 256 MiB Infinity Cache' % (
+                2 * N * ks * H_ * W_ * 4 / 1e6, 2 * N * ks * H_ * W_ * 4 / float(256 << 20)),
             'timing': 'HIP events around the launch, %d repetitions, mean (event overhead ~5 us included)' % reps}
 
 
