@@ -77,3 +77,48 @@ def test_weight_gradient_chunk_loop_keeps_its_accumulators_in_place(device_asm, 
         wide = sum(1 for l in loop if 'buffer_load_dwordx4' in l)
         assert wide == (12 if pair else 0), (name, wide)
     assert found == 1
+
+
+def test_persistent_sepconv_kernel_polls_lds_and_keeps_its_loads_in_flight(device_asm):
+    """Properties of the generated code that kernel 20 (csrc/sepconv_fwd.hip.inc, sepconv_forward_persistent) depends on and that
+    the compiler once got wrong: (1) the LDS counters are polled with ds_read, not through a generic pointer -- a flat load sits
+    behind s_waitcnt vmcnt(0), so every poll would wait for the tap loads and the patch DMA in flight; (2) the type-A tap loads
+    are 51 buffer loads off one descriptor with nothing waited for in between (per-lane 64-bit addresses were computed up front,
+    spilled and reloaded, one load at a time); (3) next to no register spills."""
+    found = 0
+    for name, lines in _kernel_bodies(device_asm, '_ZN3fwd26sepconv_forward_persistentILi0EE'):
+        found += 1
+        assert not any('flat_load' in l or 'flat_atomic' in l for l in lines), name
+        assert sum(1 for l in lines if re.search(r'\bds_add_u32\b', l)) >= 4           # ready / done bumps
+        # (a handful of spills around the row-loop blocks, whose register maps leave the compiler seven free vector registers, are
+        # tolerated; a spilled tap address array or accumulator set would be hundreds)
+        assert sum(1 for l in lines if re.search(r'\bscratch_(load|store)', l)) <= 24, name
+        # the 51 tap loads of a round: consecutive buffer_load_dwordx4, no s_waitcnt vmcnt between the first and the last
+        idx = [n for n, l in enumerate(lines) if re.search(r'\bbuffer_load_dwordx4\b', l)]
+        assert len(idx) == 51, (name, len(idx))
+        between = lines[idx[0]:idx[-1] + 1]
+        assert not any(re.search(r's_waitcnt.*vmcnt', l) for l in between), name
+        # the generated tap fold: eleven loads go out before its first counted wait
+        fold = [n for n, l in enumerate(lines) if 'v_fmac_f32' in l and 'v252' in l]
+        assert fold, name
+        pre = lines[:fold[0]]
+        last_asm = max(n for n, l in enumerate(pre) if 'ASMSTART' in l)
+        assert sum(1 for l in pre[last_asm:] if re.search(r'\bglobal_load_dwordx4\b', l)) == 11, name
+    assert found == 1
+
+
+@pytest.mark.parametrize('epi', [1, 2])
+def test_second_output_epilogue_loads_go_out_before_the_stores(device_asm, epi):
+    """The Winograd kernel's second-output epilogues (EPI 1 / 2) load the 16 values to add ahead of the inverse transform; inside
+    the store loop each was waited for where it was used (25-31 % of the wave cycles waiting: profiles/r03_wino_conv_pmc.txt)."""
+    found = 0
+    for tall in (0, 1):
+        for name, lines in _kernel_bodies(device_asm, '_ZN4wino7conv3x3ILi0ELi0ELi0ELi0ELb%dELi%dEE' % (tall, epi)):
+            found += 1
+            mf = [n for n, l in enumerate(lines) if 'v_mfma' in l]
+            ep = lines[mf[-1] + 1:]
+            stores = [n for n, l in enumerate(ep) if re.search(r'\bbuffer_store_dwordx2\b', l)]
+            loads = [n for n, l in enumerate(ep) if re.search(r'\bbuffer_load_dword\b', l)]
+            assert len(loads) >= 32 and stores, (name, len(loads))          # 16 bias + 16 add values
+            assert max(loads) < min(stores), name                            # every load is issued before the first output store
+    assert found == 2
