@@ -333,7 +333,7 @@ def cpu_baseline_and_parity(model, device, timed=3, cpu_threads=None):
     return base, parity
 
 
-def secondary_configs(device):
+def secondary_configs(device, parity=True):
     """configs[3] (TAI_color 256x256 BGR, K=F=3, T=5, batch 16) and configs[4] (TAI_gray T=10, batch 32) end to end on one
     GPU -- hipGraph replay, 2 warm + 3 timed -- and the sepconv forward at configs[3]'s shape against both of its ceilings
     (36 flop/B: above the ridge, so the fp32 vector peak is the one that binds)."""
@@ -355,6 +355,23 @@ def secondary_configs(device):
         res[name] = {'model': key, 'clips': B, 'frame': [C, H, W], 'K_T_F': [K, T, F], 'ms_per_step': round(dt * 1e3, 2),
                      'frames_per_s': round(B * T / dt, 1)}
         log('%s: %.1f ms per step, %.1f frames/s' % (name, dt * 1e3, B * T / dt))
+        if parity:
+            # one clip of this config against the CPU oracle -- the checker of bench.py's cpu_baseline leg, as in the headline's
+            # parity block; never on the measured path
+            from oracle import tai_oracle
+            sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+            Pc, GTc, Fc = (torch.from_numpy(x) for x in synthetic.split_clip(clips[:1], K, T, F))
+            with torch.no_grad():
+                ref = tai_oracle.tai_forward(sd, C, 5 if C == 1 else 4, 51, T, Pc, Fc)
+                out = m(T, Pc.to(device), Fc.to(device))
+            pg, sg, _ = metrics.compute_errors(out['pred'].cpu().numpy(), GTc.numpy())
+            pc, sc_, _ = metrics.compute_errors(ref['pred'].numpy(), GTc.numpy())
+            res[name]['parity_one_clip'] = {
+                'max_abs_over_max_ref': {k: float('%.3g' % float((out[k].cpu() - ref[k]).abs().max() / ref[k].abs().max()))
+                                         for k in ('pred', 'pred_forward', 'pred_backward')},
+                'max_abs_psnr_delta_db': float(np.max(np.abs(pg - pc))), 'max_abs_ssim_delta': float(np.max(np.abs(sg - sc_))),
+                'uint8_gray_levels_gpu': int(len(np.unique(metrics.to_uint8(out['pred'].cpu().numpy()))))}
+            log('%s parity on one clip: %s' % (name, res[name]['parity_one_clip']['max_abs_over_max_ref']))
         del g, m, P, Fo
         torch.cuda.empty_cache()
     # the three-channel sepconv forward at configs[3]'s launch shape [T*B = 80, 3, 256, 256] would be 2.3 GB of taps; the
@@ -634,7 +651,9 @@ def main():
             if not args.no_graph:
                 del graphed, step
             torch.cuda.empty_cache()
-            for key, leg in (('secondary', secondary_configs), ('train_step', train_step_leg)):
+            # (the secondary configs' one-clip check against the oracle belongs to the cpu_baseline leg: off with --no-cpu-baseline)
+            legs = (('secondary', lambda d: secondary_configs(d, parity=not args.no_cpu_baseline)), ('train_step', train_step_leg))
+            for key, leg in legs:
                 try:
                     line[key] = leg(device)
                 except Exception as e:          # an extra leg must never cost the headline line

@@ -46,7 +46,7 @@ def test_matches_reference_golden_run(golden_dir, tag):
 REL_TOL = 1e-4      # per output key: max |gpu - oracle| <= REL_TOL * max |oracle|  (fp32, different summation orders)
 
 
-def _assert_matches_oracle(out, ref, GT, name='', min_levels=50, min_spread=0.05):
+def _assert_matches_oracle(out, ref, GT, name='', min_levels=50, min_spread=0.05, rel_tol=REL_TOL):
     """Outputs within REL_TOL of the oracle relative to each key's own magnitude, AND the comparison is about something:
     the uint8 prediction spans many gray levels, PSNR vs ground truth differs between frames, and PSNR / SSIM vs ground
     truth agree between GPU and oracle (0.01 dB / 1e-4)."""
@@ -54,7 +54,7 @@ def _assert_matches_oracle(out, ref, GT, name='', min_levels=50, min_spread=0.05
         scale = float(ref[k].abs().max())
         assert scale > 0.05, (name, k, scale)                 # a near-zero reference would make the check vacuous
         err = float((out[k].cpu() - ref[k]).abs().max())
-        assert err <= REL_TOL * scale, (name, k, err, scale)
+        assert err <= rel_tol * scale, (name, k, err, scale)
     pred_gpu, pred_cpu = out['pred'].cpu().numpy(), ref['pred'].numpy()
     assert len(np.unique(metrics.to_uint8(pred_gpu))) > min_levels, name
     p_gpu, s_gpu, _ = metrics.compute_errors(pred_gpu, GT.numpy())
@@ -124,7 +124,9 @@ def test_full_width_tai_gray_long_gap_matches_cpu_oracle():
         m.to(DEV).eval()
         out = m(10, P.to(DEV), Fo.to(DEV))
         assert out['pred'].shape == (1, 10, 1, 128, 128)
-        _assert_matches_oracle(out, ref, GT, 'TAI_gray T=10 full width')
+        # ten recurrent MC-Net steps instead of five: the tanh-bounded predictions drift to 0.8-1.0e-4 of their maximum on some
+        # clips (bench.py's configs[4] check) -- inside SURVEY.md 8d's 2e-4 bound for the full model, which is the bound used here
+        _assert_matches_oracle(out, ref, GT, 'TAI_gray T=10 full width', rel_tol=2e-4)
 
 
 def test_derived_weights_follow_in_place_weight_writes():
