@@ -250,8 +250,11 @@ def _kxk_ok(N, Ci, Co, H, W, kh, kw, padding):
 WINO_MIN_WORKGROUPS = 96       # below this the 64x64-tile kernel leaves most of the 256 CUs idle and MIOpen is as fast (measured: tools/conv_path_times.py)
 
 
-def _wino_ok(N, Ci, Co, H, W, kh, kw, padding):
-    return (kh == kw == 3 and padding == 1 and H % 2 == 0 and W % 2 == 0 and Ci >= 8 and N * max(Ci, Co) * H * W < 2 ** 29
+def _wino_ok(N, Ci, Co, H, W, kh, kw, padding, min_ci=8):
+    """``min_ci``: the kernel pads the input channels to a multiple of 8 with zero weights, so fewer than 8 work -- at the cost of a
+    whole chunk; the inference paths take that down to 2 (TAI_color's first ContentEnc layer, 3 -> 64 at 256 x 256: 276 us against
+    MIOpen's 620), the training path does not (its input gradient would run 64 rows of MFMA for 3 output channels)."""
+    return (kh == kw == 3 and padding == 1 and H % 2 == 0 and W % 2 == 0 and Ci >= min_ci and N * max(Ci, Co) * H * W < 2 ** 29
             and ((N * (H // 2) * (W // 2) + 63) // 64) * ((Co + 63) // 64) >= WINO_MIN_WORKGROUPS)
 
 
@@ -688,7 +691,7 @@ def _conv_bias_act(x, weight, bias, padding, act, transposed, out):
         return y
     if not transposed and _kxk_ok(N, Ci, Co, H, W, kh, kw, padding):
         return _kxk_as_wino(x, weight, bias, act, False)
-    if _wino_ok(N, Ci, Co, H, W, kh, kw, padding):
+    if _wino_ok(N, Ci, Co, H, W, kh, kw, padding, min_ci=2):
         # Winograd F(2x2,3x3) on the fp32 MFMA pipe (csrc/wino_conv.hip.inc)
         x = x.contiguous()
         U = _wino_weights(weight, transposed)
