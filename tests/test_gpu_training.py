@@ -230,7 +230,8 @@ def test_graphed_update_matches_the_eager_update(tmp_path, monkeypatch):
         assert abs(g_err[k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, g_err[k], v)
     # --- gradients before Adam (p.grad still holds them after the step)
     report = []
-    for part, tol in (('generator', 2e-4), ('discriminator', 2e-3)):
+    # measured on the GPU box: <= 9.2e-7 of a tensor's maximum (generator), <= 1.8e-6 (discriminator, MIOpen's atomics)
+    for part, tol in (('generator', 2e-5), ('discriminator', 1e-4)):
         for (k, pe), (_, pg) in zip(getattr(eager, part).named_parameters(), getattr(graph, part).named_parameters()):
             if pe.grad is None:
                 assert pg.grad is None and k.startswith('merge_residual1'), k       # never evaluated (tai.py:224-226)
