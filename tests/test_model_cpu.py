@@ -372,3 +372,44 @@ def test_conv_bias_act_takes_channel_parts_on_cpu():
         assert torch.equal(conv_bias_act((a, b), conv.weight, conv.bias, 1, 'relu'), torch.relu(conv(torch.cat((a, b), 1))))
         y, yp = conv_bias_act_maxpool(a, torch.nn.Conv2d(8, 4, 3, padding=1).weight, conv.bias, 1, 'relu')
         assert torch.equal(yp, F.max_pool2d(y, 2))
+
+
+def test_committed_counter_summary_matches_the_library_it_would_be_quoted_for():
+    """bench.py prints `roofline.traffic` from profiles/sepconv_fwd_pmc.json only when the summary was collected on the library
+    version and default kernel that are about to be measured (otherwise null).  A kernel change that forgets to re-collect the
+    counters should fail here, not show up as a null in the driver's record."""
+    import json
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rec = json.load(open(os.path.join(root, 'profiles', 'sepconv_fwd_pmc.json')))
+    src = open(os.path.join(root, 'video-frame-inpainting_amd', 'csrc', 'sepconv_capi.hip')).read()
+    version = int(re.search(r'int tai_sepconv_version\(void\) \{ return (\d+); \}', src).group(1))
+    default = re.search(r'return !tileable \? 1 : \(C == 1 \? (\d+) : (\d+)\);', src)
+    assert rec['library_version'] == version, (rec['library_version'], version)
+    assert rec['forward_variant'] == int(default.group(1))
+    assert rec['shape'] == [32, 1, 128, 128] and 0.98 < rec['traffic_over_algorithmic'] < 1.05
+    c3 = json.load(open(os.path.join(root, 'profiles', 'sepconv_fwd_pmc_c3.json')))
+    assert c3['library_version'] == version
+
+
+def test_cpu_threads_of_the_baseline_leg_follow_affinity_quota_and_request(monkeypatch, tmp_path):
+    import bench
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(256)))
+    monkeypatch.delenv('TAI_CPU_THREADS', raising=False)
+    real_open = open
+
+    def fake_open(path, *a, **k):
+        if path == '/sys/fs/cgroup/cpu.max':
+            import io
+            return io.StringIO(fake_open.content)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr('builtins.open', fake_open)
+    fake_open.content = '1600000 100000\n'
+    n, how = bench.host_cpu_share()
+    assert n == 16 and how['cgroup_quota_cores'] == 16 and how['sched_affinity'] == 256
+    fake_open.content = 'max 100000\n'
+    assert bench.host_cpu_share()[0] == 16                 # no quota: the pool's one-GPU share
+    assert bench.host_cpu_share(64)[0] == 64               # an explicit request within the affinity
+    assert bench.host_cpu_share(1000)[0] == 256
+    fake_open.content = '400000 100000\n'
+    assert bench.host_cpu_share(64)[0] == 4                # the quota wins over a request
