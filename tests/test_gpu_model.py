@@ -129,6 +129,22 @@ def test_full_width_tai_gray_long_gap_matches_cpu_oracle():
         _assert_matches_oracle(out, ref, GT, 'TAI_gray T=10 full width', rel_tol=2e-4)
 
 
+def test_headline_forward_is_bit_reproducible():
+    """configs[1]'s forward (TAI_gray, 32 clips, hipGraph replay) takes in-tree kernels with fixed summation orders for every layer
+    -- no MIOpen kernel with atomics is left in it -- and the persistent sepconv kernel's LDS-counter synchronisation must not let
+    a stale read through: replays and an eager pass all give the same bits (tools/soak_forward.py runs thousands)."""
+    m = synthetic.seeded_init(vfi.create_model('TAI_gray'), 0).to(DEV).eval()
+    clips = synthetic.make_clips(32, 15, 1, 128, 128, synthetic.SEEDS['cfg2'])
+    P, _, Fo = (torch.from_numpy(x).to(DEV) for x in synthetic.split_clip(clips, 5, 5, 5))
+    with torch.no_grad():
+        eager = {k: v.clone() for k, v in m(5, P, Fo).items()}
+        g = GraphedForward(m, 5, P, Fo, warmup=1)
+        for _ in range(5):
+            out = g()
+            for k in KEYS:
+                assert torch.equal(out[k], eager[k]), k
+
+
 def test_derived_weights_follow_in_place_weight_writes():
     """conv_ops caches Winograd-domain / flipped weights per tensor version: a write that moves the version
     counter is seen by itself; a write through .data needs conv_ops.invalidate_derived (weights_init, the replica
