@@ -16,11 +16,14 @@ if len(sys.argv) > 2 and sys.argv[2] == 'intree':        # every 3x3 layer on th
     from video_frame_inpainting_amd import conv_ops
     conv_ops.WINO_MIN_WORKGROUPS = 0
 dev = torch.device('cuda:0')
-model = synthetic.seeded_init(vfi.create_model('TAI_gray'), 0).to(dev).eval()
-clips = synthetic.make_clips(32, 15, 1, 128, 128, synthetic.SEEDS['cfg2'])
-P, _, Fo = (torch.from_numpy(a).to(dev) for a in synthetic.split_clip(clips, 5, 5, 5))
+COLOR = 'color' in sys.argv[2:]              # configs[3]: TAI_color 256 x 256, 16 clips (three-channel sepconv kernel 19)
+LONG = 'long' in sys.argv[2:]                # configs[4]: T = 10 (640 tiles... 320 samples per sepconv launch: three rounds and more)
+model = synthetic.seeded_init(vfi.create_model('TAI_color' if COLOR else 'TAI_gray'), 0).to(dev).eval()
+K, T, F = (3, 5, 3) if COLOR else ((5, 10, 5) if LONG else (5, 5, 5))
+clips = synthetic.make_clips(16 if COLOR else 32, K + T + F, 3 if COLOR else 1, 256 if COLOR else 128, 256 if COLOR else 128, synthetic.SEEDS['cfg2'])
+P, _, Fo = (torch.from_numpy(a).to(dev) for a in synthetic.split_clip(clips, K, T, F))
 with torch.no_grad():
-    g = GraphedForward(model, 5, P, Fo, warmup=1)
+    g = GraphedForward(model, T, P, Fo, warmup=1)
     first = {k: v.clone() for k, v in g().items()}
     torch.cuda.synchronize()
     bad = 0
