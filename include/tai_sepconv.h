@@ -285,6 +285,13 @@ const char* tai_sepconv_last_error(void);
 /* Library / ABI version: major*10000 + minor*100 + patch. */
 int tai_sepconv_version(void);
 
+/* SHA-256 (hex) of the sources this binary was compiled from: every csrc/*.hip and csrc/*.inc plus this header, in sorted
+ * order, as the in-tree builder computes it (video-frame-inpainting_amd/_native.py: source_hash()).  The loader recomputes
+ * the hash from the tree next to the binary and refuses a library that was built from other sources -- the sources travel
+ * with the binary, so a stale .so (a failed rebuild, an edited kernel) cannot run.  Replaces the unconditional load of
+ * src/separable_convolution/_ext/cunnex/__init__.py:6-15.  "unknown" for a build made without the in-tree builder. */
+const char* tai_sepconv_source_hash(void);
+
 #ifdef __cplusplus
 }
 #endif

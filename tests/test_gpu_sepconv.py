@@ -157,6 +157,39 @@ def test_persistent_forward_kernel_matches_the_one_tile_kernels_bit_for_bit(B):
     assert _rel(outs[20][sl].cpu().numpy(), ref) < FWD_TOL
 
 
+@pytest.mark.parametrize('B', [160, 320])
+def test_persistent_forward_kernel_at_the_round_counts_the_product_runs(B):
+    """The launches the product makes: configs[1] / [2] call the op with T * B = 160 samples at 128 x 128 (1,280 tiles = 5 rounds
+    of 256 persistent workgroups), configs[4] (T = 10) with 320 (10 rounds).  Through the DEFAULT route (no variant forced) the
+    result must carry the same bits as kernel 16 (one tile per workgroup, kernel.cu:19-47 restated per tile), an fp64 oracle
+    slice of the LAST two samples and of two from the MIDDLE must agree to the forward tolerance, and alternating the frames
+    with their exact negation must alternate the result exactly (LDS keeps a previous round's patch and taps: a stale read
+    of either shows as a non-negated value)."""
+    ks, H, W = 51, 128, 128
+    g = torch.Generator().manual_seed(1000 + B)
+    inp = (torch.rand(B, 1, H + ks - 1, W + ks - 1, generator=g) * 2 - 1).to(DEV)
+    v = (torch.randn(B, ks, H, W, generator=g) * 0.1).to(DEV)
+    h = (torch.randn(B, ks, H, W, generator=g) * 0.1).to(DEV)
+    L = _native.lib()
+    assert L.tai_sepconv_default_forward_variant(1, W, ks) == 20     # the persistent kernel IS the default; 1,280 / 2,560 tiles > 256 CUs and % 8 == 0
+    with torch.no_grad():
+        prev = sc.set_forward_variant(16)
+        try:
+            want = vfi.SeparableConvolution.apply(inp, v, h, ks)
+            sc.set_forward_variant(0)
+            got = vfi.SeparableConvolution.apply(inp, v, h, ks)
+            assert torch.equal(got, want)
+            neg = -inp
+            for _ in range(3):
+                assert torch.equal(vfi.SeparableConvolution.apply(neg, v, h, ks), -want)
+                assert torch.equal(vfi.SeparableConvolution.apply(inp, v, h, ks), want)
+        finally:
+            sc.set_forward_variant(prev)
+    for sl in (slice(B - 2, B), slice(B // 2 - 1, B // 2 + 1)):
+        ref = so.forward(inp[sl].cpu().numpy(), v[sl].cpu().numpy(), h[sl].cpu().numpy(), ks, f64=True)
+        assert _rel(got[sl].cpu().numpy(), ref) < FWD_TOL
+
+
 @pytest.mark.parametrize('i,j', [(0, 0), (50, 50), (25, 3), (1, 48), (49, 2)])
 def test_delta_taps_shift_exactly(i, j):
     B, C, H, W, ks = 1, 1, 16, 128, 51

@@ -18,9 +18,29 @@ MAIN_SOURCE = os.path.join(CSRC, 'sepconv_capi.hip')          # the one translat
 GENERATED = os.path.join(CSRC, 'sepconv_fwd_rowloop.inc')     # written by tools/gen_fwd_asm.py
 
 
-def sources():
-    """Every file under csrc/: the staleness check covers whatever the translation unit includes, listed or not."""
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.startswith('.'))
+def sources(csrc=None):
+    """Every source file under csrc/ (*.hip, *.inc): the staleness check and the source hash cover whatever the translation
+    unit includes, listed or not.  Editor backups and the generator's transient '<name>.tmp.<pid>' are not sources."""
+    csrc = csrc or CSRC
+    return sorted(os.path.join(csrc, f) for f in os.listdir(csrc)
+                  if f.endswith(('.hip', '.inc')) and not f.startswith('.') and '.tmp.' not in f)
+
+
+def source_hash(csrc=None, header=None):
+    """SHA-256 over (file name, length, bytes) of every source under csrc/ and of include/tai_sepconv.h, in sorted order: what
+    build() compiles into the library (tai_sepconv_source_hash()) and what lib() recomputes from the tree before it trusts a
+    binary.  Contents only -- no mtimes, no paths -- so the hash survives the copy to the GPU box."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sources(csrc) + [header or HEADER]:
+        try:
+            with open(path, 'rb') as f:
+                data = f.read()
+        except FileNotFoundError:        # vanished between listdir and open (a concurrent generator run): not a source
+            continue
+        h.update(os.path.basename(path).encode() + b'\0' + str(len(data)).encode() + b'\0')
+        h.update(data)
+    return h.hexdigest()
 
 
 _lib = None
@@ -47,16 +67,49 @@ def build(force=False, verbose=False, timing=False):
     only tools/ links or loads it."""
     out = TIMING_LIB_PATH if timing else LIB_PATH
     regenerate()
-    newest = max(os.path.getmtime(p) for p in sources() + [HEADER])
-    if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+    want = source_hash()
+    if not force and os.path.exists(out) and embedded_source_hash(out) == want:
         return out
     os.makedirs(os.path.dirname(out), exist_ok=True)
+    # the old binary goes first: a compile that fails must leave NOTHING to load (round 3's one GPU fault was a stale library
+    # that survived a failed rebuild); the new one is written beside the target and renamed over it only when hipcc succeeded
+    if os.path.exists(out):
+        os.remove(out)
+    tmp = out + '.building.%d' % os.getpid()
     cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-slp-vectorize', '-w',
-           '-I' + os.path.join(_ROOT, 'include'), '-o', out, MAIN_SOURCE] + (['-DTAI_TIMING_VARIANTS'] if timing else [])
+           '-I' + os.path.join(_ROOT, 'include'), '-DTAI_SOURCE_HASH="%s"' % want, '-o', tmp, MAIN_SOURCE] + \
+          (['-DTAI_TIMING_VARIANTS'] if timing else [])
     if verbose:
         print(' '.join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        if source_hash() != want:
+            raise NativeLibraryError('csrc/ changed while %s was compiling: build again' % os.path.basename(out))
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return out
+
+
+def embedded_source_hash(path):
+    """The hash a built library carries (None if it cannot be loaded or predates tai_sepconv_source_hash)."""
+    try:
+        L = ctypes.CDLL(path)
+        f = L.tai_sepconv_source_hash
+    except (OSError, AttributeError):
+        return None
+    f.restype = ctypes.c_char_p
+    return f().decode()
+
+
+def verify(path, csrc=None, header=None):
+    """Raise NativeLibraryError unless the library at `path` was compiled from exactly the sources in the tree."""
+    have, want = embedded_source_hash(path), source_hash(csrc, header)
+    if have != want:
+        raise NativeLibraryError(
+            '%s was not built from the sources next to it (library: %s, tree: %s): a stale binary must not run -- rebuild with '
+            '`python -c "import __graft_entry__ as g; g.build()"`' % (path, have, want))
 
 
 def regenerate():
@@ -79,6 +132,7 @@ def lib():
             '%s is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             '(there is no fallback path for the separable convolution)' % path)
     import torch  # noqa: F401  -- load torch's HIP runtime first so this library binds to the same libamdhip64
+    verify(path)
     L = ctypes.CDLL(path)
     missing = [s for s in declared_symbols() if not hasattr(L, s)]
     if missing:
@@ -163,6 +217,7 @@ def lib():
     L.tai_sepconv_backward_bytes.argtypes = [I] * 5
     L.tai_sepconv_backward_bytes.restype = ctypes.c_longlong
     L.tai_sepconv_last_error.restype = ctypes.c_char_p
+    L.tai_sepconv_source_hash.restype = ctypes.c_char_p
     L.tai_sepconv_version.restype = I
     _lib = L
     return L

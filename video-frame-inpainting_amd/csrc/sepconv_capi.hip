@@ -262,6 +262,11 @@ int tai_sepconv_version(void) { return 320; }     // 0.3.2: forward kernels 18 /
 
 const char* tai_sepconv_last_error(void) { return g_err; }
 
+#ifndef TAI_SOURCE_HASH
+#define TAI_SOURCE_HASH "unknown"
+#endif
+const char* tai_sepconv_source_hash(void) { return TAI_SOURCE_HASH; }     // -DTAI_SOURCE_HASH="..." from _native.build()
+
 int tai_sepconv_set_forward_variant(int variant) { return g_fwd_variant.exchange(variant, std::memory_order_relaxed); }
 
 int tai_sepconv_set_grad_taps_variant(int variant) { return g_vh_variant.exchange(variant, std::memory_order_relaxed); }
