@@ -86,8 +86,16 @@ def test_persistent_sepconv_kernel_polls_lds_and_keeps_its_loads_in_flight(devic
     are 51 buffer loads off one descriptor with nothing waited for in between (per-lane 64-bit addresses were computed up front,
     spilled and reloaded, one load at a time); (3) next to no register spills."""
     found = 0
-    for name, lines in _kernel_bodies(device_asm, '_ZN3fwd26sepconv_forward_persistentILi0EE'):
+    for name, lines in _kernel_bodies(device_asm, '_ZN3fwd26sepconv_forward_persistentILi0E'):
         found += 1
+        # <DBG 0, NT, REV>: round 4's instantiations with non-temporal tap loads carry `nt` on every once-read tap stream -- the 51
+        # type-A buffer loads, the 51 fold loads and the v planes' LDS-DMA (the 2 x 12 patch DMAs keep the default policy)
+        nt = 'Lb1ELb' in name
+        for pat, want in ((r'\bbuffer_load_dwordx4\b', 51), (r'\bglobal_load_dwordx4\b', 51)):
+            hits = [l for l in lines if re.search(pat, l)]
+            assert len(hits) == want and sum(1 for l in hits if re.search(r'\bnt\b', l)) == (want if nt else 0), (name, pat)
+        dma = [l for l in lines if 'global_load_lds_dwordx4' in l]
+        assert sum(1 for l in dma if re.search(r'\bnt\b', l)) == (len(dma) - 24 if nt else 0), name
         assert not any('flat_load' in l or 'flat_atomic' in l for l in lines), name
         assert sum(1 for l in lines if re.search(r'\bds_add_u32\b', l)) >= 4           # ready / done bumps
         # (a handful of spills around the row-loop blocks, whose register maps leave the compiler seven free vector registers, are
@@ -104,7 +112,7 @@ def test_persistent_sepconv_kernel_polls_lds_and_keeps_its_loads_in_flight(devic
         pre = lines[:fold[0]]
         last_asm = max(n for n, l in enumerate(pre) if 'ASMSTART' in l)
         assert sum(1 for l in pre[last_asm:] if re.search(r'\bglobal_load_dwordx4\b', l)) == 11, name
-    assert found == 1
+    assert found == 3              # <NT, REV> = <0, 0>, <1, 0>, <1, 1>
 
 
 @pytest.mark.parametrize('epi', [1, 2])

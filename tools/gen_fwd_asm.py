@@ -57,6 +57,11 @@ S_SLOT_WR = 's68'        # byte offset of the slot the DMA fills    = ((fy + RIN
 S_T0, S_T1 = 's69', 's70'
 
 
+NT = ''      # ' nt' while the *_NT variants are generated: once-read tap streams of launches whose tap footprint exceeds the
+             # Infinity Cache (the persistent forward kernel) load non-temporally -- 7.0-7.2 TB/s against 6.3-6.5 on a 1.2 GB sweep
+             # (profiles/r04_hbm_stream_microbench.txt)
+
+
 def pair(r):
     return 'v[%d:%d]' % (r, r + 1)
 
@@ -127,7 +132,7 @@ def emit_row(L, phase):
     L.append('s_add_u32 %s, %s, %s' % (S_T0, S_RINGM0, S_SLOT_WR))
     L.append('s_mov_b32 m0, %s' % S_T0)
     L.append('s_nop 0')
-    L.append('global_load_lds_dwordx4 v%d, s[64:65]' % V_GOFF)
+    L.append('global_load_lds_dwordx4 v%d, s[64:65]%s' % (V_GOFF, NT))
     L.append('s_cmp_lt_u32 %s, %d' % (S_ROW, KS - 1 - RING))
     L.append('s_cselect_b32 %s, %s, 0' % (S_T1, S_PLANE))
     L.append('s_add_u32 %s, %s, %s' % (S_PTR_LO, S_PTR_LO, S_T1))
@@ -168,7 +173,7 @@ def gen():
         L.append('s_add_u32 %s, %s, %d' % (S_T0, S_RINGM0, r * 1024))
         L.append('s_mov_b32 m0, %s' % S_T0)
         L.append('s_nop 0')
-        L.append('global_load_lds_dwordx4 v%d, s[64:65]' % V_GOFF)
+        L.append('global_load_lds_dwordx4 v%d, s[64:65]%s' % (V_GOFF, NT))
         L.append('s_add_u32 %s, %s, %s' % (S_PTR_LO, S_PTR_LO, S_PLANE))
         L.append('s_addc_u32 %s, %s, 0' % (S_PTR_HI, S_PTR_HI))
     # s[64:65] now points at row RING
@@ -242,7 +247,7 @@ def emit_row_b(L, phase):
     L.append('s_add_u32 %s, %s, %s' % (S_T0, S_RINGM0, S_SLOT_WR))
     L.append('s_mov_b32 m0, %s' % S_T0)
     L.append('s_nop 0')
-    L.append('global_load_lds_dwordx4 v%d, s[64:65]' % V_GOFF)
+    L.append('global_load_lds_dwordx4 v%d, s[64:65]%s' % (V_GOFF, NT))
     L.append('s_cmp_lt_u32 %s, %d' % (S_ROW, KS - 1 - RING))
     L.append('s_cselect_b32 %s, %s, 0' % (S_T1, S_PLANE))
     L.append('s_add_u32 %s, %s, %s' % (S_PTR_LO, S_PTR_LO, S_T1))
@@ -274,7 +279,7 @@ def gen_b():
         L.append('s_add_u32 %s, %s, %d' % (S_T0, S_RINGM0, r * 1024))
         L.append('s_mov_b32 m0, %s' % S_T0)
         L.append('s_nop 0')
-        L.append('global_load_lds_dwordx4 v%d, s[64:65]' % V_GOFF)
+        L.append('global_load_lds_dwordx4 v%d, s[64:65]%s' % (V_GOFF, NT))
         L.append('s_add_u32 %s, %s, %s' % (S_PTR_LO, S_PTR_LO, S_PLANE))
         L.append('s_addc_u32 %s, %s, 0' % (S_PTR_HI, S_PTR_HI))
     L.append('s_mov_b32 %s, 0' % S_ROW)
@@ -346,7 +351,7 @@ def gen_fold():
 
     def issue(t):
         base = FOLD_BASES[t % FOLD_BUFS]
-        L.append('global_load_dwordx4 v[%d:%d], v%d, s[64:65]' % (base, base + 3, V_GOFF))
+        L.append('global_load_dwordx4 v[%d:%d], v%d, s[64:65]%s' % (base, base + 3, V_GOFF, NT))
         L.append('s_add_u32 %s, %s, %s' % (S_PTR_LO, S_PTR_LO, S_PLANE))
         L.append('s_addc_u32 %s, %s, 0' % (S_PTR_HI, S_PTR_HI))
     for t in range(FOLD_BUFS):
@@ -644,7 +649,7 @@ def gen_gi():
 
 
 def main():
-    global LOOKAHEAD, NBUF, ABLATE_VMCNT, ABLATE_LGKM, PRIO_ALTERNATE
+    global LOOKAHEAD, NBUF, ABLATE_VMCNT, ABLATE_LGKM, PRIO_ALTERNATE, NT
     here = os.path.dirname(os.path.abspath(__file__))
     out = os.path.join(here, '..', 'video-frame-inpainting_amd', 'csrc', 'sepconv_fwd_rowloop.inc')
     variants = [('TAI_FWD_ROWLOOP_ASM', 3, 4, False, False),
@@ -656,10 +661,13 @@ def main():
         f.write('// GENERATED by tools/gen_fwd_asm.py -- do not edit.  Register map and schedule: see the generator.\n')
         f.write('#define TAI_FWD_ROWLOOP_RING_SLOTS %d\n' % SLOTS)
         variants.append(('TAI_FWD_ROWLOOP_ASM_PRIO', 3, 4, False, False))   # type A next to a type-B partner
+        variants.append(('TAI_FWD_ROWLOOP_ASM_PRIO_NT', 3, 4, False, False))   # the same, v planes loaded non-temporally
         for name, la, nbuf, novm, nolgkm in variants:
             LOOKAHEAD, NBUF, ABLATE_VMCNT, ABLATE_LGKM = la, nbuf, novm, nolgkm
-            PRIO_ALTERNATE = name.endswith('_PRIO')
+            PRIO_ALTERNATE = '_PRIO' in name
+            NT = ' nt' if name.endswith('_NT') else ''
             lines = gen()
+            NT = ''
             n_pk = sum(1 for l in lines if l.startswith('v_pk_'))
             f.write('// %s: ks=%d ring=%d slots=%d lookahead=%d buffers=%d; %d instructions, %d packed.\n'
                     % (name, KS, RING, SLOTS, LOOKAHEAD, NBUF, len(lines), n_pk))
@@ -668,24 +676,30 @@ def main():
                 f.write('    "%s\\n" \\\n' % l)
             f.write('    ""\n')
         LOOKAHEAD, NBUF, ABLATE_VMCNT, ABLATE_LGKM, PRIO_ALTERNATE = 3, 4, False, False, False
-        lines = gen_b()
-        f.write('// TAI_FWD_ROWLOOP_B_ASM (accumulators resident, taps last): %d instructions.\n' % len(lines))
-        f.write('#define TAI_FWD_ROWLOOP_B_ASM \\\n')
-        for l in lines:
-            f.write('    "%s\\n" \\\n' % l)
-        f.write('    ""\n')
+        for suffix in ('', '_NT'):
+            NT = ' nt' if suffix else ''
+            lines = gen_b()
+            NT = ''
+            f.write('// TAI_FWD_ROWLOOP_B_ASM%s (accumulators resident, taps last): %d instructions.\n' % (suffix, len(lines)))
+            f.write('#define TAI_FWD_ROWLOOP_B_ASM%s \\\n' % suffix)
+            for l in lines:
+                f.write('    "%s\\n" \\\n' % l)
+            f.write('    ""\n')
         lines = gen_gv()
         f.write('// TAI_GV_ROWLOOP_ASM (gV = gO * row sums, one store per row): %d instructions.\n' % len(lines))
         f.write('#define TAI_GV_ROWLOOP_ASM \\\n')
         for l in lines:
             f.write('    "%s\\n" \\\n' % l)
         f.write('    ""\n')
-        lines = gen_fold()
-        f.write('// TAI_FWD_FOLD_ASM (type-B tap fold of the persistent kernel, %d loads in flight): %d instructions.\n' % (FOLD_BUFS, len(lines)))
-        f.write('#define TAI_FWD_FOLD_ASM \\\n')
-        for l in lines:
-            f.write('    "%s\\n" \\\n' % l)
-        f.write('    ""\n')
+        for suffix in ('', '_NT'):
+            NT = ' nt' if suffix else ''
+            lines = gen_fold()
+            NT = ''
+            f.write('// TAI_FWD_FOLD_ASM%s (type-B tap fold of the persistent kernel, %d loads in flight): %d instructions.\n' % (suffix, FOLD_BUFS, len(lines)))
+            f.write('#define TAI_FWD_FOLD_ASM%s \\\n' % suffix)
+            for l in lines:
+                f.write('    "%s\\n" \\\n' % l)
+            f.write('    ""\n')
         clob_fold = ['v%d' % r for b in FOLD_BASES for r in range(b, b + 4)] + ['s64', 's65', 'scc', 'memory']
         f.write('#define TAI_FWD_FOLD_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob_fold))
         lines = gen_c3()

@@ -93,14 +93,16 @@ def build(force=False, verbose=False, timing=False):
 
 
 def embedded_source_hash(path):
-    """The hash a built library carries (None if it cannot be loaded or predates tai_sepconv_source_hash)."""
+    """The hash a built library carries, read from the FILE (the marker 'TAI_SOURCE_HASH=' in front of it): nothing is mapped, so
+    a binary about to be refused never runs a constructor, and dlopen's by-name cache cannot answer for a file that was rebuilt
+    since.  None if the file is missing or carries no hash (any library from before this check)."""
     try:
-        L = ctypes.CDLL(path)
-        f = L.tai_sepconv_source_hash
-    except (OSError, AttributeError):
+        with open(path, 'rb') as f:
+            data = f.read()
+    except OSError:
         return None
-    f.restype = ctypes.c_char_p
-    return f().decode()
+    m = re.search(rb'TAI_SOURCE_HASH=([0-9a-f]{64})\0', data)
+    return m.group(1).decode() if m else None
 
 
 def verify(path, csrc=None, header=None):

@@ -156,8 +156,12 @@ static int device_cu_count() {
 
 // kernel 20: one persistent workgroup per CU over the tiles of a single-channel frame batch; falls back to kernel 18 when there
 // is at most one tile per CU (nothing to overlap) or the tile count is not a multiple of 8 (the XCD-contiguous tile order)
+// POLICY: 0 = by footprint (nt loads and the reversed tile walk when the two tap tensors together exceed the Infinity Cache:
+// every tap byte is read once and none of it will be there for anybody else), 1 = default cache policy, forward walk (round 3's
+// kernel 20), 2 = nt, forward walk, 3 = nt, reversed walk.
 template <int DBG = 0>
-int fwd_persistent(const float* in, const float* v, const float* h, float* out, int B, int C, int H, int W, hipStream_t s, bool force) {
+int fwd_persistent(const float* in, const float* v, const float* h, float* out, int B, int C, int H, int W, hipStream_t s, bool force,
+                   int policy = 0) {
     const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W, tiles_y = (H + 15) / 16;
     const int ntiles = B * tiles_x * tiles_y;
     const int cus = device_cu_count();
@@ -167,9 +171,17 @@ int fwd_persistent(const float* in, const float* v, const float* h, float* out, 
     if (grid > ntiles) grid = ntiles;
     const size_t patch = ((size_t)(16 + 50) * 180 * sizeof(float) + 1023) & ~(size_t)1023;
     const size_t lds = 2 * patch + (size_t)8 * TAI_FWD_ROWLOOP_RING_SLOTS * 1024 + 16;
-    auto kern = fwd::sepconv_forward_persistent<DBG>;
-    if (int rc = allow_lds(kern, lds)) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, in, v, h, out, H, W, tiles_x, tiles_y, ntiles);
+    if (policy == 0) policy = (2LL * B * 51 * H * W * 4 > (256LL << 20)) ? 3 : 1;
+#define TAI_LAUNCH_PERSISTENT(NT, REV)                                                                              \
+    {                                                                                                               \
+        auto kern = fwd::sepconv_forward_persistent<DBG, NT, REV>;                                                  \
+        if (int rc = allow_lds(kern, lds)) return rc;                                                               \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, in, v, h, out, H, W, tiles_x, tiles_y, ntiles);     \
+    }
+    if (policy == 3) TAI_LAUNCH_PERSISTENT(true, true)
+    else if (policy == 2) TAI_LAUNCH_PERSISTENT(true, false)
+    else TAI_LAUNCH_PERSISTENT(false, false)
+#undef TAI_LAUNCH_PERSISTENT
     return check_launch("sepconv_forward_persistent");
 }
 
@@ -258,14 +270,17 @@ int launch_grad_vh_tiled(const float* gO, const float* in, const float* v, const
 
 extern "C" {
 
-int tai_sepconv_version(void) { return 320; }     // 0.3.2: forward kernels 18 / 20 (persistent where tiles > CUs) for C == 1, 19 for C > 1
+int tai_sepconv_version(void) { return 400; }     // 0.4.0: persistent forward kernel with nt tap loads + reversed walk beyond the Infinity Cache; source hash
 
 const char* tai_sepconv_last_error(void) { return g_err; }
 
 #ifndef TAI_SOURCE_HASH
 #define TAI_SOURCE_HASH "unknown"
 #endif
-const char* tai_sepconv_source_hash(void) { return TAI_SOURCE_HASH; }     // -DTAI_SOURCE_HASH="..." from _native.build()
+// -DTAI_SOURCE_HASH="..." from _native.build().  The marker in front lets the loader read the hash from the FILE, without mapping
+// a binary it may be about to refuse (and without dlopen's by-name cache handing back a library that was since rebuilt).
+static const char k_source_hash[] = "TAI_SOURCE_HASH=" TAI_SOURCE_HASH;
+const char* tai_sepconv_source_hash(void) { return k_source_hash + 16; }
 
 int tai_sepconv_set_forward_variant(int variant) { return g_fwd_variant.exchange(variant, std::memory_order_relaxed); }
 
@@ -327,6 +342,9 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 17: return fwd_asm_three_channels<false>(input, vertical, horizontal, output, B, C, H, W, s);
         case 19: return fwd_asm_three_channels<true>(input, vertical, horizontal, output, B, C, H, W, s);
         case 20: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, g_fwd_variant.load(std::memory_order_relaxed) == 20);
+        case 21: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 1);   // A/B: default cache policy, forward walk
+        case 22: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 2);   // A/B: nt tap loads, forward walk
+        case 23: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 3);   // A/B: nt tap loads, reversed walk
 #ifdef TAI_TIMING_VARIANTS   // timing experiments (wrong results by design): tools/ build only, never in the shipped library
         case 108: return fwd_ab_all_channels<3, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 109: return fwd_ab_all_channels<4, 3>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 16 with stamps
