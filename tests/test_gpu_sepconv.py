@@ -62,7 +62,7 @@ def test_forward_and_backward_match_oracle(B, C, H, W, ks):
     assert _rel(out.detach().cpu().numpy(), lit.astype(np.float64)) < 2 * FWD_TOL
 
 
-@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23])
+@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
 @pytest.mark.parametrize('C', [1, 3])
 def test_every_forward_variant(variant, C):
     inp, v, h, _ = _case(2, C, 24, 128, 51, 5)
@@ -142,7 +142,7 @@ def test_persistent_forward_kernel_matches_the_one_tile_kernels_bit_for_bit(B):
     with torch.no_grad():
         # 21 / 22 / 23: the persistent kernel with the default cache policy, with nt tap loads, with nt loads and the tile list
         # walked backwards (20 picks between 21 and 23 by the tap footprint)
-        for variant in (16, 18, 20, 21, 22, 23):
+        for variant in (16, 18, 20, 21, 22, 23, 24):
             prev = sc.set_forward_variant(variant)
             try:
                 outs[variant] = vfi.SeparableConvolution.apply(inp, v, h, ks)
@@ -153,7 +153,7 @@ def test_persistent_forward_kernel_matches_the_one_tile_kernels_bit_for_bit(B):
                         assert torch.equal(vfi.SeparableConvolution.apply(inp, v, h, ks), outs[variant])
             finally:
                 sc.set_forward_variant(prev)
-    assert all(torch.equal(outs[k], outs[16]) for k in (18, 20, 21, 22, 23))
+    assert all(torch.equal(outs[k], outs[16]) for k in (18, 20, 21, 22, 23, 24))
     sl = slice(B - 2, B)
     ref = so.forward(inp[sl].cpu().numpy(), v[sl].cpu().numpy(), h[sl].cpu().numpy(), ks, f64=True)
     assert _rel(outs[20][sl].cpu().numpy(), ref) < FWD_TOL

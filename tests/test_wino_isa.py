@@ -41,16 +41,24 @@ def test_counted_waits_match_the_loads_behind_the_last_dma(device_asm, parts, ta
         bars = [n for n, l in enumerate(lines) if 's_barrier' in l]
         segs = [lines[a + 1:b + 1] for a, b in zip([-1] + bars[:-1], bars)]
         dma_segs = [s for s in segs if any('global_load_lds_dwordx4' in l for l in s)]
-        assert len(dma_segs) == 4, (name, len(dma_segs))         # prologue, the two loop bodies, the odd trailing chunk
+        assert len(dma_segs) == 5, (name, len(dma_segs))         # prologue, chunk 0 (peeled), the two loop bodies, the trailing chunk
         waits = [[int(m.group(1)) for l in s for m in [re.search(r's_waitcnt vmcnt\((\d+)\)', l)] if m][-1] for s in dma_segs]
-        assert waits[0] == 0, 'prologue must wait for everything issued'
-        for s, w in zip(dma_segs[1:3], waits[1:3]):
+        # prologue (round 4): only the weight DMA must have landed at the barrier; the patch loads of chunk 1 are issued behind it
+        # and stay in flight -- 3 loads per patch row, 8 rows (two patches per thread) or 4 (one): the wait must count exactly them
+        pro = dma_segs[0]
+        last = max(n for n, l in enumerate(pro) if 'global_load_lds_dwordx4' in l)
+        behind = sum(1 for l in pro[last:] if re.search(r'\bbuffer_load_dword', l))
+        assert behind == waits[0] == (12 if tall else 24), (name, behind, waits[0])
+        # and no load sits between the prologue's barrier and the first MFMA (round 3: 24 of them, 1,300 cycles)
+        first_mfma = next(n for n, l in enumerate(dma_segs[1]) if 'v_mfma' in l)
+        assert not any(re.search(r'\bbuffer_load', l) for l in dma_segs[1][:first_mfma]), name
+        for s, w in zip(dma_segs[1:4], waits[1:4]):
             last = max(n for n, l in enumerate(s) if 'global_load_lds_dwordx4' in l)
             behind = sum(1 for l in s[last:] if re.search(r'\bbuffer_load_dword', l))
             assert sum(1 for l in s if 'global_load_lds_dwordx4' in l) == dmas
             assert behind == w == 12, (name, behind, w)
         # no register spills in the channel loop (they would sit on the MFMA critical path)
-        for s in dma_segs[1:3]:
+        for s in dma_segs[1:4]:
             assert not any(re.search(r'\bscratch_(load|store)', l) for l in s), name
     assert found == 1
 
@@ -112,7 +120,7 @@ def test_persistent_sepconv_kernel_polls_lds_and_keeps_its_loads_in_flight(devic
         pre = lines[:fold[0]]
         last_asm = max(n for n, l in enumerate(pre) if 'ASMSTART' in l)
         assert sum(1 for l in pre[last_asm:] if re.search(r'\bglobal_load_dwordx4\b', l)) == 11, name
-    assert found == 3              # <NT, REV> = <0, 0>, <1, 0>, <1, 1>
+    assert found == 4              # <NT, REV> = <0, 0>, <0, 1>, <1, 0>, <1, 1>
 
 
 @pytest.mark.parametrize('epi', [1, 2])
@@ -127,6 +135,6 @@ def test_second_output_epilogue_loads_go_out_before_the_stores(device_asm, epi):
             ep = lines[mf[-1] + 1:]
             stores = [n for n, l in enumerate(ep) if re.search(r'\bbuffer_store_dwordx2\b', l)]
             loads = [n for n, l in enumerate(ep) if re.search(r'\bbuffer_load_dword\b', l)]
-            assert len(loads) >= 32 and stores, (name, len(loads))          # 16 bias + 16 add values
+            assert len(loads) == 16 and stores, (name, len(loads))          # the 16 add values (the bias entered through accumulator block 5)
             assert max(loads) < min(stores), name                            # every load is issued before the first output store
     assert found == 2

@@ -65,6 +65,21 @@ def main():
                 for _ in range(R):
                     keep.append(sep(inp, v, h, KS))
             graphs[var] = (g32, g160, gbb)
+        # (d) as bench.py times the in-model launch: eager, the two producing convolutions then the sepconv, HIP events around the sepconv alone
+        for rnd in range(2):
+            for var in VARIANTS:
+                sc.set_forward_variant(var)
+                pairs = []
+                for rep in range(13):
+                    conv_ops.conv_bias_act(x51, w51, b51, 1, None, out=v); conv_ops.conv_bias_act(x51, w51, b51, 1, None, out=h)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); keep.append(sep(inp, v, h, KS)); e1.record()
+                    pairs.append((e0, e1))
+                torch.cuda.synchronize()
+                ts = sorted(a.elapsed_time(b2) * 1e3 for a, b2 in pairs[3:])
+                print('events %d kernel %d: in-model [160,1,128,128] behind its two convolutions: mean %.1f us (min %.1f, max %.1f) = %.3f' % (
+                    rnd, var, float(np.mean(ts)), ts[0], ts[-1], 1100311040.0 / float(np.mean(ts)) / 8e6), flush=True)
+                del keep[-13:]
         sc.set_forward_variant(0)
         for rnd in range(3):
             base = replay_us(gb)

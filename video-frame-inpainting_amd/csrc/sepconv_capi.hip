@@ -158,7 +158,7 @@ static int device_cu_count() {
 // is at most one tile per CU (nothing to overlap) or the tile count is not a multiple of 8 (the XCD-contiguous tile order)
 // POLICY: 0 = by footprint (nt loads and the reversed tile walk when the two tap tensors together exceed the Infinity Cache:
 // every tap byte is read once and none of it will be there for anybody else), 1 = default cache policy, forward walk (round 3's
-// kernel 20), 2 = nt, forward walk, 3 = nt, reversed walk.
+// kernel 20), 2 = nt, forward walk, 3 = nt, reversed walk, 4 = default cache policy, reversed walk.
 template <int DBG = 0>
 int fwd_persistent(const float* in, const float* v, const float* h, float* out, int B, int C, int H, int W, hipStream_t s, bool force,
                    int policy = 0) {
@@ -179,6 +179,7 @@ int fwd_persistent(const float* in, const float* v, const float* h, float* out, 
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, in, v, h, out, H, W, tiles_x, tiles_y, ntiles);     \
     }
     if (policy == 3) TAI_LAUNCH_PERSISTENT(true, true)
+    else if (policy == 4) TAI_LAUNCH_PERSISTENT(false, true)
     else if (policy == 2) TAI_LAUNCH_PERSISTENT(true, false)
     else TAI_LAUNCH_PERSISTENT(false, false)
 #undef TAI_LAUNCH_PERSISTENT
@@ -345,6 +346,7 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 21: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 1);   // A/B: default cache policy, forward walk
         case 22: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 2);   // A/B: nt tap loads, forward walk
         case 23: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 3);   // A/B: nt tap loads, reversed walk
+        case 24: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 4);   // A/B: default cache policy, reversed walk
 #ifdef TAI_TIMING_VARIANTS   // timing experiments (wrong results by design): tools/ build only, never in the shipped library
         case 108: return fwd_ab_all_channels<3, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 109: return fwd_ab_all_channels<4, 3>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 16 with stamps
