@@ -29,6 +29,10 @@ for level in levels:
             ghz = np.median(tot / np.maximum(t[:, 61] - t[:, 60], 1)) * 0.1      # shader cycles per 100 MHz tick
             print('x(%d,%d,%d,%d)->%d [%s]: %d workgroups, %d chunks; clocks: prologue %.0f  loop %.0f (%.0f/chunk; ideal 4096)  epilogue %.0f  total %.0f  shader clock %.2f GHz'
                   % (N, C, H, W, K, '128 x 32' if tall else '64 x 64', wgs, (C + 7) // 8, np.median(pro), np.median(loop), np.median(loop) / max((C + 7) // 8, 1), np.median(epi), np.median(tot), ghz))
+            sub = [np.median(t[:, 40] - t[:, 0]), np.median(t[:, 41] - t[:, 40]), np.median(t[:, 42] - t[:, 41]), np.median(t[:, 43] - t[:, 42]),
+                   np.median(t[:, 44] - t[:, 43]), np.median(t[:, 1] - t[:, 44]), np.median(t[:, 45] - t[:, 2]), np.median(t[:, 3] - t[:, 45])]
+            print('   prologue: set-up %.0f | loads + DMA issued %.0f | accumulator init %.0f | chunk 0 landed + transformed %.0f | LDS writes %.0f | waits + barrier %.0f'
+                  '     epilogue: inverse transform %.0f | activation + stores %.0f' % tuple(sub))
             print('   per-chunk median by index:', ' '.join('%.0f' % v for v in np.median(ch, axis=0)[:16]), ' p90 of all chunks %.0f' % np.percentile(ch, 90), flush=True)
 L.tai_conv3x3_wino_timeline_skip(0)
 L.tai_conv3x3_wino_set_tall(1)
