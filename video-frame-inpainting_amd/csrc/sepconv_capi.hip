@@ -819,6 +819,24 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
     const int pmode = S ? 2 : (nparts > 1 ? 1 : 0);
 #define TAI_WINO_ARGS xs[0], xs[1], xs[2], xs[3], cpart, U, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, Kpad, nchunks
     const int part_magic = S ? (1 << 20) / (cpart / 8) + 1 : 0;     // chunk -> channel block of the displaced reads
+    // n / d == (n * m) >> (32 + s) for every n < 2^31: s = floor(log2 d), one less for a power of two (m = 2^31, exact); for any
+    // other d, 2^s < d gives m = ceil(2^(32+s) / d) < 2^32 and an error term e = m d - 2^(32+s) < d, so n e < 2^(32+s) holds for
+    // n <= 2^(32+s) / d, which exceeds 2^31.  d == 1 is flagged by m == 0.
+    auto magic = [](long long d, unsigned& m, unsigned& sh) {
+        if (d <= 1) { m = 0; sh = 0; return; }
+        int lg = 0;
+        while ((2LL << lg) <= d) ++lg;                          // floor(log2 d)
+        if ((1LL << lg) == d) --lg;
+        sh = (unsigned)lg;
+        const unsigned __int128 num = (unsigned __int128)1 << (32 + lg);
+        m = (unsigned)((num + (unsigned __int128)d - 1) / (unsigned __int128)d);
+    };
+    wino::DivMagic dvF, dvT;
+    magic((long long)(H / 2) * (W / 2), dvF.m_tpi, dvF.s_tpi);
+    magic(W / 2, dvF.m_tw, dvF.s_tw);
+    magic(kblocks, dvF.m_kb, dvF.s_kb);
+    dvT = dvF;
+    magic(Kpad / wino::TTM > 0 ? Kpad / wino::TTM : 1, dvT.m_kb, dvT.s_kb);
 #define TAI_WINO_TAIL stamps, pool_h, pool_w, pool_oy, pool_ox, ex.addx, ex.y2, S, part_magic, ex.zero_tail
 #define TAI_LAUNCH_WINO(A, D, SK, Q, E)                                                                                  \
     do {                                                                                                               \
@@ -827,11 +845,11 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
             const int tkb = Kpad / wino::TTM;                                                                          \
             if (int rc = allow_lds(wino::conv3x3<A, D, SK, Q, true, E>, wino::TLDS_BYTES)) return rc;                  \
             hipLaunchKernelGGL((wino::conv3x3<A, D, SK, Q, true, E>), dim3((unsigned)(ttb * tkb)), dim3(256), wino::TLDS_BYTES, s, \
-                               TAI_WINO_ARGS, tkb, TAI_WINO_TAIL);                                                     \
+                               TAI_WINO_ARGS, tkb, TAI_WINO_TAIL, dvT);                                                \
         } else {                                                                                                       \
             if (int rc = allow_lds(wino::conv3x3<A, D, SK, Q, false, E>, wino::LDS_BYTES)) return rc;                  \
             hipLaunchKernelGGL((wino::conv3x3<A, D, SK, Q, false, E>), dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::LDS_BYTES, s, \
-                               TAI_WINO_ARGS, kblocks, TAI_WINO_TAIL);                                                 \
+                               TAI_WINO_ARGS, kblocks, TAI_WINO_TAIL, dvF);                                            \
         }                                                                                                              \
     } while (0)
 #define TAI_LAUNCH_WINO_ACT(D, SK, Q)                                   \
