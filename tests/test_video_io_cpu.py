@@ -153,3 +153,27 @@ def test_gif_sequence_and_dataset_pipeline_on_an_avi(tmp_path):
     assert it['clip_label'] == 'person01_boxing_d1.avi_2-8'
     want = torch.from_numpy(fr[1:8, :, :, ::-1].copy()).permute(0, 3, 1, 2).float() / 255 * 2 - 1
     assert torch.allclose(it['targets'], want, atol=1e-6)
+
+
+@pytest.mark.parametrize('bits, cut_to', [(24, 8), (8, 30), (8, 40 + 4 * 100)])
+def test_a_truncated_stream_header_warns_and_returns_none(tmp_path, bits, cut_to):
+    """a corrupt AVI must not kill a DataLoader worker with struct.error.  The stream format chunk is cut to 8 bytes (no
+    BITMAPINFOHEADER), to 30 bytes (8-bit: no colour count) and inside the palette: open_frame_source warns and returns None, as
+    the reference does for an unreadable video (src/data/base_dataset.py:118-127) -- the dataset then samples another clip."""
+    good = tmp_path / 'good.avi'
+    write_avi(str(good), _frames(), b'\x00\x00\x00\x00', bits=bits)
+    blob = good.read_bytes()
+    at = blob.index(b'strf')
+    size = struct.unpack('<I', blob[at + 4:at + 8])[0]
+    assert cut_to < size
+    # keep the chunk's declared size consistent with what is left of it (a cleanly truncated chunk), and also try the declared
+    # size left as it was (the parser then sees the following chunks' bytes as header: still no exception type other than IOError)
+    for keep_declared in (False, True):
+        head = blob[:at + 4] + (blob[at + 4:at + 8] if keep_declared else struct.pack('<I', cut_to)) + blob[at + 8:at + 8 + cut_to]
+        bad = tmp_path / ('bad_%d_%d.avi' % (cut_to, keep_declared))
+        bad.write_bytes(head if keep_declared else head + blob[at + 8 + size:])
+        with pytest.raises(IOError):
+            video_io.open_video_file(str(bad))
+        with pytest.warns(UserWarning, match='Failed to open video'):
+            assert vdata.open_frame_source(str(bad)) is None
+    assert vdata.open_frame_source(str(good)).get_length() == 6

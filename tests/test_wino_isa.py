@@ -43,12 +43,16 @@ def test_counted_waits_match_the_loads_behind_the_last_dma(device_asm, parts, ta
         dma_segs = [s for s in segs if any('global_load_lds_dwordx4' in l for l in s)]
         assert len(dma_segs) == 5, (name, len(dma_segs))         # prologue, chunk 0 (peeled), the two loop bodies, the trailing chunk
         waits = [[int(m.group(1)) for l in s for m in [re.search(r's_waitcnt vmcnt\((\d+)\)', l)] if m][-1] for s in dma_segs]
-        # prologue (round 4): only the weight DMA must have landed at the barrier; the patch loads of chunk 1 are issued behind it
-        # and stay in flight -- 3 loads per patch row, 8 rows (two patches per thread) or 4 (one): the wait must count exactly them
+        # prologue (round 4): only the weight DMA must have landed at the barrier; the middle pairs of chunk 1's patches are issued
+        # behind it and stay in flight -- ONE load per patch row (the outer values go out before the DMA, and only if a lane of the
+        # wave needs them), 8 rows (two patches per thread) or 4 (one): the wait must count exactly them
         pro = dma_segs[0]
         last = max(n for n, l in enumerate(pro) if 'global_load_lds_dwordx4' in l)
         behind = sum(1 for l in pro[last:] if re.search(r'\bbuffer_load_dword', l))
-        assert behind == waits[0] == (12 if tall else 24), (name, behind, waits[0])
+        assert behind == waits[0] == (4 if tall else 8), (name, behind, waits[0])
+        # every kernel argument of the prologue arrives in ONE batch of scalar loads: a single lgkmcnt wait before the first patch load
+        first_load = next(n for n, l in enumerate(pro) if re.search(r'\bbuffer_load_dword', l))
+        assert sum(1 for l in pro[:first_load] if re.search(r's_waitcnt.*lgkmcnt', l)) <= 2, name
         # and no load sits between the prologue's barrier and the first MFMA (round 3: 24 of them, 1,300 cycles)
         first_mfma = next(n for n, l in enumerate(dma_segs[1]) if 'v_mfma' in l)
         assert not any(re.search(r'\bbuffer_load', l) for l in dma_segs[1][:first_mfma]), name

@@ -19,6 +19,8 @@ import random
 import re
 from warnings import warn
 
+import struct
+
 import numpy as np
 import torch
 import torch.utils.data as data
@@ -77,7 +79,7 @@ def open_frame_source(path):
             from .video_io import open_video_file                   # AVI (uncompressed / Motion-JPEG / PNG), GIF, TIFF, ...
             return open_video_file(path)
         return imageio.get_reader(path, 'ffmpeg')
-    except (IOError, OSError, ImportError, KeyError, ValueError) as e:
+    except (IOError, OSError, ImportError, KeyError, ValueError, struct.error) as e:
         warn('Failed to open video %s: %s' % (path, e))
         return None
 

@@ -21,7 +21,7 @@ import torch.distributed as dist
 def init_from_env(backend=None, local_rank=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (set by torch.distributed.run).
     Returns (rank, world_size, local_rank); a single un-launched process gets (0, 1, 0) and no group.  ``backend`` and
-    ``local_rank`` override what the environment implies (tools/rehearse_ranks_one_gpu.py: gloo, every rank on cuda:0)."""
+    ``local_rank`` override what the environment implies (`python bench.py --gpus 2 --rehearse-one-gpu`: gloo, every rank on cuda:0)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0')) if local_rank is None else local_rank

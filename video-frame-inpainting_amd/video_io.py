@@ -69,10 +69,19 @@ class AviVideo(object):
             elif fourcc == b'strh':
                 self._cur_is_video = bytes(data[body:body + 4]) == b'vids' and self._stream is None
             elif fourcc == b'strf' and getattr(self, '_cur_is_video', False) and self._fmt is None:
+                # a truncated or corrupt header is an I/O error of THIS file (the caller warns and samples another clip, as the
+                # reference does, base_dataset.py:118-127), not a struct.error that kills the loader worker
+                avail = min(body + size, end, len(data)) - body
+                if avail < 20:
+                    raise IOError('%s: truncated AVI header (stream format chunk of %d bytes)' % (self._filename, max(avail, 0)))
                 (hsize, width, height, planes, bits, comp) = struct.unpack('<IiiHH4s', bytes(data[body:body + 20]))
                 palette = None
                 if bits == 8:
+                    if avail < 36:
+                        raise IOError('%s: truncated AVI header (no colour count in an 8-bit stream format)' % self._filename)
                     ncol = struct.unpack('<I', bytes(data[body + 32:body + 36]))[0] or 256
+                    if hsize < 40 or hsize + 4 * ncol > avail:
+                        raise IOError('%s: truncated AVI header (palette of %d colours does not fit its chunk)' % (self._filename, ncol))
                     pal = np.frombuffer(bytes(data[body + hsize:body + hsize + 4 * ncol]), np.uint8).reshape(-1, 4)
                     palette = pal[:, [2, 1, 0]].copy() if pal.shape[0] else None          # BGRA -> RGB
                 self._fmt = (width, abs(height), bits, comp, height < 0, palette)
