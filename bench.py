@@ -472,6 +472,93 @@ def train_step_leg(device, B=32, timed=3):
     return out
 
 
+def train_step_dist_leg(device, rank, world, B=32, timed=3, rehearsal=False):
+    """configs[2] as BASELINE.json states it: the TAI_gray G-then-D update data-parallel over the ranks of one node, 32 clips per rank
+    (global batch 32 x world), gradients averaged by the two bucketed all-reduces of parallel.GradAllReducer (generator 153.3 MB, then
+    discriminator 11.2 MB, /root/reference/src/environments/environments.py:348-355's order) launched from backward's hooks over RCCL.
+    Every rank runs it; rank 0 returns the record: ms per update (MAX over ranks, barrier + synchronize on both sides), all-reduce
+    bytes per update, the exposed communication (device time the compute stream waited in allreduce_(), parallel.py), and the replica
+    identity check -- after the timed updates every rank's parameter checksum must be the same number (max |delta| == 0).
+    rehearsal: the same code on CPU over gloo with a reduced model (tests/test_bench_launch.py): plumbing only, never a measurement."""
+    import contextlib
+    import tempfile
+    import torch.distributed as dist
+    from video_frame_inpainting_amd.environments import create_training_environment
+    if rehearsal:
+        Hh, Ww, K, T, F = 32, 32, 3, 2, 3
+        torch.manual_seed(7 + rank)                     # replicas start DIFFERENT: sync_replicas must fix that
+        model = vfi.MCNetFillInModel(4, 1, 3)           # (the sepconv op has no CPU form; the G/D step, buckets and hooks are the same)
+        env_args = (1, tempfile.mkdtemp(prefix='tai_bench_'), 'bench%d' % rank, K, T, F, [Hh, Ww], 1.0, 0.02, 1e-3, 0.5, 4, 2, 3, [0, 0])
+    else:
+        Hh, Ww, K, T, F = H_, W_, K_, T_, F_
+        model = vfi.create_model('TAI_gray')
+        env_args = (1, tempfile.mkdtemp(prefix='tai_bench_'), 'bench%d' % rank, K, T, F, [Hh, Ww], 1.0, 0.02, 1e-4, 0.5, 64, 3, 3, [0, 0])
+    with contextlib.redirect_stdout(sys.stderr):
+        env = create_training_environment(model, *env_args, device=device)
+    env.sync_replicas()
+    clips = torch.from_numpy(synthetic.make_clips(B, K + T + F, C_, Hh, Ww, synthetic.SEEDS['cfg3'] + rank))     # each rank its own clips
+    P, GT, Fo = synthetic.split_clip(clips, K, T, F)
+    on_gpu = torch.device(device).type == 'cuda'
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    def step():
+        env.K, env.T, env.F = K, T, F
+        env.train()
+        env.train_step(P, Fo, GT)
+    t0 = time.perf_counter()
+    step(); sync()
+    first = time.perf_counter() - t0
+    step(); sync()
+    env._reducer_G.timing, env._reducer_D.timing = [], []
+    dist.barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        step()
+    sync(); dist.barrier()
+    dt = torch.tensor([(time.perf_counter() - t0) / timed], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    nbytes_G = sum(p.numel() * p.element_size() for p in env._reducer_G.params)
+    nbytes_D = sum(p.numel() * p.element_size() for p in env._reducer_D.params)
+    exposed = None
+    if on_gpu:
+        per = [sum(a.elapsed_time(b2) for a, b2 in r.timing) / max(timed, 1) for r in (env._reducer_G, env._reducer_D)]
+        ex = torch.tensor(per, dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        exposed = {'generator_ms': round(float(ex[0]), 3), 'discriminator_ms': round(float(ex[1]), 3),
+                   'what': 'device time between the events bracketing allreduce_() on the compute stream (wait for the buckets still '
+                           'in flight when backward ends + the divide kernels), per update, MAX over ranks'}
+    # replica identity: one float64 checksum of every generator and discriminator parameter (and the spectral-norm u vectors) per rank
+    with torch.no_grad():
+        vecs = [p.detach().double().reshape(-1) for p in list(env.generator.parameters()) + list(env.discriminator.parameters())]
+        vecs += [m.u.detach().double().reshape(-1) for m in env.discriminator.modules() if getattr(m, 'u', None) is not None]
+        flat = torch.cat(vecs)
+        w = torch.arange(1, flat.numel() + 1, dtype=torch.float64, device=flat.device)
+        check = torch.stack([flat.sum(), (flat * (w % 8191)).sum()]).to(device if dist.get_backend() == 'nccl' else 'cpu')
+    gathered = [torch.empty_like(check) for _ in range(world)]
+    dist.all_gather(gathered, check)
+    delta = max(float((g - gathered[0]).abs().max()) for g in gathered)
+    errs = env.get_current_errors()
+    out = {'workload': 'configs[2]: TAI_gray G+D update, data parallel over %d ranks, %d clips per rank (global batch %d), 128x128 K=T=F=5, '
+                       'alpha 1 beta 0.02 lr 1e-4 Ip 3 disc_t 3 df_dim 64, fp32' % (world, B, world * B),
+           'ranks': world, 'backend': ('rccl (torch.distributed "nccl")' if dist.get_backend() == 'nccl' else dist.get_backend()),
+           'ms_per_update': round(float(dt) * 1e3, 1), 'clips_per_s': round(world * B / float(dt), 1), 'updates_timed': timed,
+           'first_update_s': round(first, 2),
+           'allreduce_bytes_per_update': {'generator': nbytes_G, 'discriminator': nbytes_D,
+                                          'buckets': [len(env._reducer_G.buckets), len(env._reducer_D.buckets)]},
+           'exposed_communication': exposed,
+           'replica_checksum_max_abs_delta': delta, 'replicas_identical': delta == 0.0,
+           'losses_finite': bool(all(np.isfinite(v) for v in errs.values()))}
+    if rehearsal:
+        out['workload'] = 'REHEARSAL on CPU over gloo (reduced MC-Net model, 32x32): plumbing of the leg above, not a measurement'
+    del env
+    if on_gpu:
+        torch.cuda.empty_cache()
+    return out if rank == 0 else None
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -531,8 +618,15 @@ def rehearse_launch(args):
     dt = torch.tensor([1.0 + rank], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    train = None
+    if args.rehearse_train and world > 1:               # the multi-rank training leg's plumbing, on CPU (reduced model)
+        _imports()
+        train = train_step_dist_leg('cpu', rank, world, B=2, timed=2, rehearsal=True)
     if rank == 0:
-        print(json.dumps({'rehearsal': True, 'n_gpus': world, 'ranks': world, 'backend': 'gloo', 'max_dt': float(dt.item())}), flush=True)
+        rec = {'rehearsal': True, 'n_gpus': world, 'ranks': world, 'backend': 'gloo', 'max_dt': float(dt.item())}
+        if train is not None:
+            rec['train_step_dp'] = train
+        print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -548,9 +642,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--miopen-find', action='store_true', help='let MIOpen benchmark its algorithms during warm-up')
     ap.add_argument('--rehearse-launch', action='store_true', help='CPU/gloo rehearsal of the rank launch only (tests)')
+    ap.add_argument('--rehearse-train', action='store_true', help='with --rehearse-launch: also the multi-rank training leg on CPU/gloo')
     ap.add_argument('--rehearse-one-gpu', action='store_true',
                     help='N ranks all on cuda:0 with gloo for the control plane: a rehearsal of the N-rank code path on a '
                          'one-GPU box; the line is marked "rehearsal" and is never a measurement')
+    ap.add_argument('--train-leg-timeout', type=int, default=420, help='seconds the multi-rank training leg may take before rank 0 prints the line without it')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary-config and training-update legs (extra keys of the line)')
     ap.add_argument('--cpu-threads', type=int, default=None, help='threads of the cpu_baseline leg (default: see host_cpu_share)')
     args = ap.parse_args()
@@ -659,6 +755,40 @@ def main():
                 except Exception as e:          # an extra leg must never cost the headline line
                     line[key] = {'error': '%s: %s' % (type(e).__name__, e)}
                     log('%s leg failed: %r' % (key, e))
+    if world > 1 and B == 32 and not args.no_extras and not args.rehearse_one_gpu:
+        # configs[2] is the one config with a collective: measured whenever there are peers (every rank takes part; rank 0 reports).
+        # The headline above is already measured and must reach stdout whatever happens here: the leg runs in a worker thread under
+        # a deadline; if a rank fails or a collective never completes, rank 0 prints the line with the error and every rank leaves.
+        import threading
+        del model, P, Fo
+        if not args.no_graph:
+            del graphed, step
+        torch.cuda.empty_cache()
+        box = {}
+
+        def work():
+            try:
+                torch.cuda.set_device(device)
+                box['rec'] = train_step_dist_leg(device, rank, world)
+            except Exception as e:
+                box['rec'] = {'error': '%s: %s' % (type(e).__name__, e)}
+                log('train_step_dp leg failed on rank %d: %r' % (rank, e))
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(args.train_leg_timeout)
+        hung = th.is_alive()
+        failed = hung or (isinstance(box.get('rec'), dict) and 'error' in box['rec'])
+        if rank == 0:
+            line['train_step_dp'] = {'error': 'no result within %d s (a rank failed or a collective did not complete)' % args.train_leg_timeout} \
+                if hung else box.get('rec')
+            print(json.dumps(line), flush=True)
+        if failed:
+            # peers may still sit in a collective this rank will never join: no further rendezvous, leave at once (exit code 0: the
+            # headline measurement stands; the error is in the line and in the log)
+            log('rank %d leaves without the final barrier (train_step_dp %s)' % (rank, 'timed out' if hung else 'failed'))
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
+    elif rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -98,6 +98,7 @@ class GradAllReducer(object):
             cur_bytes += nbytes
         if cur:
             self.buckets.append(cur)
+        self.timing = None           # a list: allreduce_() appends (start, end) device events (bench.py: exposed communication)
         self._flat = None            # per bucket: the flat gradient buffer
         self._pending = None         # per bucket: gradients still to arrive this step
         self._work = None            # per bucket: the async all-reduce handle, once launched
@@ -159,6 +160,21 @@ class GradAllReducer(object):
 
     # ---- both forms
     def allreduce_(self):
+        """Launch what has not been launched, wait, divide by the world size; returns the bytes reduced.  With ``self.timing`` set to a
+        list, a pair of device events brackets the call on the current stream: backward's kernels are already queued in front of
+        the first, the optimizer's behind the second, so their distance is the time the compute stream stood waiting for the
+        collectives (plus the divide kernels) -- the communication the backward pass did not hide."""
+        ev = None
+        if self.timing is not None and self.params and self.params[0].is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        total = self._allreduce()
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
+        return total
+
+    def _allreduce(self):
         world = world_size()
         if self._armed:
             self._armed = False
