@@ -279,6 +279,13 @@ int tai_sepconv_set_grad_taps_variant(int variant);
 long long tai_sepconv_forward_bytes(int B, int C, int H, int W, int ks);
 long long tai_sepconv_backward_bytes(int B, int C, int H, int W, int ks);
 
+/* Measurement utility (bench.py): one in-order streaming read of `bytes` (>= 1 MiB, 16-byte aligned) of device memory, 16 bytes
+ * per lane with eight loads in flight, default cache policy (nt == 0) or non-temporal loads (nt != 0); `sink` holds 4096 floats and
+ * is not written for ordinary data.  Asynchronous on the stream; time it with events.  No counterpart in the reference: it is the
+ * yardstick the separable convolution's in-model launch (SeparableConvolution_kernel.cu:19-47 over 1.07 GB of once-read taps) is
+ * held against on the box it runs on. */
+int tai_hbm_read_probe(const void* buffer, long long bytes, int nt, float* sink, void* hip_stream);
+
 /* Text of the last error on the calling thread ("" if none). */
 const char* tai_sepconv_last_error(void);
 

@@ -218,6 +218,8 @@ def lib():
     L.tai_sepconv_forward_bytes.restype = ctypes.c_longlong
     L.tai_sepconv_backward_bytes.argtypes = [I] * 5
     L.tai_sepconv_backward_bytes.restype = ctypes.c_longlong
+    L.tai_hbm_read_probe.argtypes = [P, ctypes.c_longlong, I, P, V]
+    L.tai_hbm_read_probe.restype = I
     L.tai_sepconv_last_error.restype = ctypes.c_char_p
     L.tai_sepconv_source_hash.restype = ctypes.c_char_p
     L.tai_sepconv_version.restype = I

@@ -21,6 +21,7 @@
 #include "wino_conv.hip.inc"
 #include "wino_wrw.hip.inc"
 #include "spectral_norm.hip.inc"
+#include "hbm_probe.hip.inc"
 
 namespace {
 
@@ -364,6 +365,16 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
 #endif
         default: return fail(TAI_SEPCONV_EINVAL, "%s", "unknown forward variant (values >= 100 exist only in the tools build, -DTAI_TIMING_VARIANTS)");
     }
+}
+
+int tai_hbm_read_probe(const void* buffer, long long bytes, int nt, float* sink, void* hip_stream) {
+    g_err[0] = 0;
+    if (!buffer || !sink || bytes < (1 << 20)) return fail(TAI_SEPCONV_EINVAL, "%s", "hbm_read_probe: needs a buffer of at least 1 MiB and a sink of 4096 floats");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const size_t n4 = (size_t)bytes / 16;
+    if (nt) hipLaunchKernelGGL(probe::stream_read<true>, dim3(4096), dim3(256), 0, s, static_cast<const probe::f4v*>(buffer), sink, n4);
+    else hipLaunchKernelGGL(probe::stream_read<false>, dim3(4096), dim3(256), 0, s, static_cast<const probe::f4v*>(buffer), sink, n4);
+    return check_launch("hbm_read_probe");
 }
 
 int tai_bias_act_inplace(float* x, const float* bias, int N, int C, int HW, int act, void* hip_stream) {
