@@ -57,7 +57,9 @@ if __name__ == '__main__':
                 env['MIOPEN_FIND_MODE'] = mode
             # a private, empty user db per child: every mode starts from the same (cold) state
             import tempfile
-            env['MIOPEN_USER_DB_PATH'] = tempfile.mkdtemp(prefix='miopen_db_')
+            # TAI_PROBE_DB=<dir>: every child shares that user find-db (first child fills it, the others start from it)
+            env['MIOPEN_USER_DB_PATH'] = os.environ.get('TAI_PROBE_DB') or tempfile.mkdtemp(prefix='miopen_db_')
+            os.makedirs(env['MIOPEN_USER_DB_PATH'], exist_ok=True)
             env['MIOPEN_CUSTOM_CACHE_DIR'] = tempfile.mkdtemp(prefix='miopen_cache_')
             t0 = time.time()
             r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=900)
