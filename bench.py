@@ -481,7 +481,8 @@ def train_step_leg(device, B=32, timed=3):
     t0 = time.perf_counter()
     step()
     torch.cuda.synchronize()
-    log('training: first update %.1f s' % (time.perf_counter() - t0))
+    first_update_s = time.perf_counter() - t0
+    log('training: first update %.1f s (MIOPEN_FIND_MODE=%s)' % (first_update_s, os.environ.get('MIOPEN_FIND_MODE')))
     step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -508,6 +509,7 @@ def train_step_leg(device, B=32, timed=3):
     errs = env.get_current_errors()
     out = {'workload': 'configs[2] per-GPU share: TAI_gray G+D update, %d clips 128x128 K=T=F=5, alpha 1 beta 0.02 lr 1e-4 Ip 3 disc_t 3 df_dim 64, fp32' % B,
            'ms_per_update': round(dt * 1e3, 1), 'clips_per_s': round(B / dt, 1), 'updates_timed': timed,
+           'first_update_s': round(first_update_s, 2), 'miopen_find_mode': os.environ.get('MIOPEN_FIND_MODE'),
            'kernel_ms': {k: round(v, 1) for k, v in sorted(split.items(), key=lambda kv: -kv[1])},
            'kernel_ms_total': round(total, 1), 'kernel_launches': int(launches),
            'peak_memory_GB': round(torch.cuda.max_memory_allocated(device) / 1e9, 1),
@@ -590,7 +592,7 @@ def train_step_dist_leg(device, rank, world, B=32, timed=3, rehearsal=False):
                        'alpha 1 beta 0.02 lr 1e-4 Ip 3 disc_t 3 df_dim 64, fp32' % (world, B, world * B),
            'ranks': world, 'backend': ('rccl (torch.distributed "nccl")' if dist.get_backend() == 'nccl' else dist.get_backend()),
            'ms_per_update': round(float(dt) * 1e3, 1), 'clips_per_s': round(world * B / float(dt), 1), 'updates_timed': timed,
-           'first_update_s': round(first, 2),
+           'first_update_s': round(first, 2), 'miopen_find_mode': os.environ.get('MIOPEN_FIND_MODE'),
            'allreduce_bytes_per_update': {'generator': nbytes_G, 'discriminator': nbytes_D,
                                           'buckets': [len(env._reducer_G.buckets), len(env._reducer_D.buckets)]},
            'exposed_communication': exposed,

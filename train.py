@@ -10,6 +10,7 @@ outside the hot path.
   python train.py --name demo --K 5 --T 5 --F 5 --c_dim 1 --image_size 128 --batch_size 4 --model_key TAI_gray \
       --max_iter 10 --synthetic 64
 """
+import os
 import time
 
 import numpy as np
@@ -24,6 +25,8 @@ from video_frame_inpainting_amd.options import TrainOptions
 
 def main(args=None):
     opt = TrainOptions().parse(args, allow_unknown=True)
+    if getattr(opt, 'miopen_find_mode', None):          # before the first convolution reaches MIOpen
+        os.environ['MIOPEN_FIND_MODE'] = opt.miopen_find_mode
     rank, world, local_rank = parallel.init_from_env()
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)

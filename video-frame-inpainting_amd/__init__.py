@@ -9,9 +9,19 @@ Layout (mirrors the reference's modules for this path):
   metrics, synthetic          PSNR/SSIM definition of the reference; seeded synthetic clips
   graph, parallel             hipGraph capture; clip-sharded data parallelism over RCCL
 """
-from .create_model import create_model, supported_model_keys  # noqa: F401
-from .separable_convolution import SeparableConvolution  # noqa: F401
-from .tai import TAIFillInModel  # noqa: F401
-from .mcnet import MCNetFillInModel  # noqa: F401
+import os as _os
+
+# MIOpen (behind torch's convolutions: on this path only the discriminator's 4x4 stride-2 layers and shapes the in-tree kernels
+# decline) benchmarks EVERY applicable solver the first time it meets a configuration -- reference kernels at 230-260 ms each among
+# them: 22-23 s of the first training update, per process, at every start, and a populated user find-db does not shorten it
+# (profiles/r04_first_update_find_modes.txt, r04_first_update_find_db.txt).  FAST takes the solver the find-db or MIOpen's heuristic
+# names without the search: first update 1.4 s, later updates 2-3 % slower (279-281 ms against 273-274).  An explicit
+# MIOPEN_FIND_MODE in the environment, or train.py --miopen_find_mode NORMAL for a long run, overrides this default.
+_os.environ.setdefault('MIOPEN_FIND_MODE', 'FAST')
+
+from .create_model import create_model, supported_model_keys  # noqa: F401,E402
+from .separable_convolution import SeparableConvolution  # noqa: F401,E402
+from .tai import TAIFillInModel  # noqa: F401,E402
+from .mcnet import MCNetFillInModel  # noqa: F401,E402
 
 __version__ = '0.1.0'

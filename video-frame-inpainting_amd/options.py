@@ -80,6 +80,9 @@ class TrainOptions(BaseOptions):
                        help='Sample the number of preceding, middle, and following frames in each minibatch')
         g.add_argument('--graph_step', action='store_true',
                        help='Capture one whole update as a hipGraph per (K, T, F) and replay it (one process per node only)')
+        g.add_argument('--miopen_find_mode', type=str, default=None, choices=['NORMAL', 'FAST', 'HYBRID', 'DYNAMIC_HYBRID'],
+                       help='MIOPEN_FIND_MODE for this run (package default FAST: first update 1.4 s instead of 22 s, later updates '
+                            '2-3 %% slower; NORMAL pays the search once and is the choice for a long run)')
         g = self.parser.add_argument_group('Training visualization parameters')
         g.add_argument('--tensorboard_dir', type=str, default='tb')
 
