@@ -701,7 +701,7 @@ int tai_conv3x3_wino_wrw_timeline(const float* x, const float* dy, float* dw, fl
 
 struct WinoExtras {                       // optional arguments of the general entry point (tai_conv3x3_wino_forward_ex)
     int shift_s = 0;                      // > 0: ONE input tensor read shift_s x shift_s times, displaced by (3a, 3b)
-    int zero_tail = 0;                    // zero tap rows / columns of the k x k filter's last 3 x 3 block: 3 S - k (0, 1 or 2)
+    int zero_tail = 0;                    // the k x k filter's last block has an all-zero third tap row / column (k % 3 != 0)
     int pool_h = 0, pool_w = 0, pool_oy = 0, pool_ox = 0;     // ypool plane and origin (0: H/2 x W/2 at (0, 0))
     const float* addx = nullptr;          // y2 = y + fixed_unpooling(addx)
     float* y2 = nullptr;
@@ -786,13 +786,13 @@ int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_k,
     WinoExtras ex;
 #ifdef TAI_TIMING_VARIANTS
     if (g_wino_ex_stamps && shift_s) {     // tools build: the next displaced-read launch writes timeline stamps (ReLU kernels only)
-        ex.shift_s = shift_s; ex.zero_tail = 3 * shift_s - shift_k;
+        ex.shift_s = shift_s; ex.zero_tail = (3 * shift_s > shift_k) ? 1 : 0;
         long long* st = g_wino_ex_stamps;
         g_wino_ex_stamps = nullptr;
         return wino_forward_impl(p, nparts, U, bias, y, N, C, K, H, W, act, hip_stream, st, nullptr, in_h, in_w, in_oy, in_ox, ex);
     }
 #endif
-    ex.shift_s = shift_s; ex.zero_tail = shift_k ? 3 * shift_s - shift_k : 0; ex.pool_h = pool_h; ex.pool_w = pool_w; ex.pool_oy = pool_oy; ex.pool_ox = pool_ox; ex.addx = addx; ex.y2 = y2;
+    ex.shift_s = shift_s; ex.zero_tail = (shift_k && 3 * shift_s > shift_k) ? 1 : 0; ex.pool_h = pool_h; ex.pool_w = pool_w; ex.pool_oy = pool_oy; ex.pool_ox = pool_ox; ex.addx = addx; ex.y2 = y2;
     return wino_forward_impl(p, nparts, U, bias, y, N, C, K, H, W, act, hip_stream, nullptr, ypool, in_h, in_w, in_oy, in_ox, ex);
 }
 
