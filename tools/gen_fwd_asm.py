@@ -422,7 +422,7 @@ def emit_row_c3(L, phase):
     queue = [('chunk', j) for j in range(LOOKAHEAD)]
 
     def wait_for(op):
-        L.append('s_waitcnt lgkmcnt(%d)' % (len(queue) - 1 - queue.index(op)))
+        L.append('s_waitcnt lgkmcnt(%d)' % (15 if ABLATE_LGKM else len(queue) - 1 - queue.index(op)))
 
     # DMA of row fy + 1 into the other slot, at once: its occupant (row fy - 1) went to registers a row ago.  Row fy's own
     # values were requested at the start of row fy - 1 and are read from the ring only at chunk C3_V_AT of channel 0, behind
@@ -447,7 +447,8 @@ def emit_row_c3(L, phase):
                 emit_chunk_read_c3(L, nj - total, base + total, True)
             queue.append(('chunk', nj))
             if c == 0 and k == C3_V_AT:
-                L.append('s_waitcnt vmcnt(1)')                             # row fy of v has landed (row fy + 1 may be in flight)
+                if not ABLATE_VMCNT:
+                    L.append('s_waitcnt vmcnt(1)')                         # row fy of v has landed (row fy + 1 may be in flight)
                 L.append('v_add_u32 v%d, %s, v%d' % (V_TMP, S_SLOT_RD, V_RING))
                 L.append('ds_read_b128 v[%d:%d], v%d' % (VV, VV + 3, V_TMP))
                 L.append('s_xor_b32 %s, %s, 1024' % (S_SLOT_RD, S_SLOT_RD))
@@ -710,6 +711,16 @@ def main():
         for l in lines:
             f.write('    "%s\\n" \\\n' % l)
         f.write('    ""\n')
+        # timing experiments (tools build only, results wrong): the same loop without the v-ring wait / without the window waits --
+        # which of the two the three-channel kernel's 25 % of waiting cycles belong to
+        for suffix, novm, nolgkm in (('_NOVM', True, False), ('_NOLGKM', False, True)):
+            ABLATE_VMCNT, ABLATE_LGKM = novm, nolgkm
+            lines = gen_c3()
+            ABLATE_VMCNT, ABLATE_LGKM = False, False
+            f.write('#define TAI_FWD_ROWLOOP_C3_ASM%s \\\n' % suffix)
+            for l in lines:
+                f.write('    "%s\\n" \\\n' % l)
+            f.write('    ""\n')
         clob_c3 = ['v%d' % r for r in list(range(204, 212)) + list(range(220, 236)) + [243, 244, 245, 246, 247, 248, 249, 250]]
         clob_c3 += ['s%d' % r for r in range(64, 71)] + ['scc', 'memory']
         f.write('#define TAI_FWD_ROWLOOP_C3_CLOBBERS %s\n' % ', '.join('"%s"' % c for c in clob_c3))

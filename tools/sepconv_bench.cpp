@@ -91,7 +91,7 @@ static void timeit(int B, int C, int H, int W, int iters) {
         const double us = ms * 1e3 / n;
         printf("  fwd variant %d [%d,%d,%d,%d]: %.1f us/call  %.2f TB/s algorithmic (%.1f%% of 8 TB/s)\n", var, B, C, H, W, us, fb / us / 1e6, fb / us / 1e6 / 8 * 100);
     }
-    for (int var : {101, 102, 111, 112}) {   // timing experiments: 101 = no tap loads, 102 = tap loads only, 111/112 = wait ablations
+    for (int var : {101, 102, 111, 112, 117, 118}) {   // timing experiments: 101 = no tap loads, 102 = tap loads only, 111/112 = wait ablations (C = 1), 117/118 = the same of kernel 19 (C = 3: no v-ring wait / no window waits)
         if (!want(var)) continue;
         tai_sepconv_set_forward_variant(var);
         for (int i = 0; i < 3; ++i) tai_sepconv_forward(din, dv, dh, dout, B, C, H, W, ks, nullptr);

@@ -201,11 +201,11 @@ int fwd_asm_channel_loop(const float* in, const float* v, const float* h, float*
 }
 
 // channels in groups of three through the three-patch row loop; what is left over through the per-channel loop
-template <bool EARLY>
+template <bool EARLY, int ABL = 0>
 int fwd_asm_three_channels(const float* in, const float* v, const float* h, float* out, int B, int C, int H, int W, hipStream_t s) {
     const int tiles_x = (W + fwd::TILE_W - 1) / fwd::TILE_W, tiles_y = (H + 15) / 16;
     const size_t lds = (size_t)3 * TAI_FWD_ROWLOOP_C3_PATCH_BYTES + (size_t)8 * TAI_FWD_ROWLOOP_C3_RING_SLOTS * 1024;
-    auto kern = fwd::sepconv_forward_asm_c3<EARLY>;
+    auto kern = fwd::sepconv_forward_asm_c3<EARLY, ABL>;
     if (int rc = allow_lds(kern, lds)) return rc;
     int c0 = 0;
     for (; c0 + 3 <= C; c0 += 3) {
@@ -349,6 +349,8 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 23: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 3);   // A/B: nt tap loads, reversed walk
         case 24: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 4);   // A/B: default cache policy, reversed walk
 #ifdef TAI_TIMING_VARIANTS   // timing experiments (wrong results by design): tools/ build only, never in the shipped library
+        case 117: return fwd_asm_three_channels<true, 1>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 19 without the v-ring wait
+        case 118: return fwd_asm_three_channels<true, 2>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 19 without the window waits
         case 108: return fwd_ab_all_channels<3, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 109: return fwd_ab_all_channels<4, 3>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 16 with stamps
         case 110: return fwd_ab_all_channels<5, 3>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 18 with stamps
