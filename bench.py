@@ -802,7 +802,7 @@ def main():
                 except Exception as e:          # an extra leg must never cost the headline line
                     line[key] = {'error': '%s: %s' % (type(e).__name__, e)}
                     log('%s leg failed: %r' % (key, e))
-    if world > 1 and B == 32 and not args.no_extras and not args.rehearse_one_gpu:
+    if world > 1 and B == 32 and not args.no_extras:       # (also in the one-GPU rehearsal: the line is then marked as such)
         # configs[2] is the one config with a collective: measured whenever there are peers (every rank takes part; rank 0 reports).
         # The headline above is already measured and must reach stdout whatever happens here: the leg runs in a worker thread under
         # a deadline; if a rank fails or a collective never completes, rank 0 prints the line with the error and every rank leaves.
