@@ -221,6 +221,17 @@ int tai_conv3x3_wino_forward_parts(const float* const* xs, int nparts, const flo
 int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_k, const float* U, const float* bias, float* y,
                                 float* ypool, int pool_h, int pool_w, int pool_oy, int pool_ox, const float* addx, float* y2, int N,
                                 int C, int K, int H, int W, int in_h, int in_w, int in_oy, int in_ox, int act, void* hip_stream);
+/* Arithmetic of the Winograd GEMMs, process-wide.  0 (default): fp32 MFMA -- the reference's arithmetic class (cuDNN fp32 behind
+ * nn.Conv2d, src/models/mcnet/mcnet.py:28-224) and the one every parity statement of this library is made on.  1 (opt-in): SPLIT
+ * bf16 -- each fp32 operand as three bf16 terms, a product as six bf16 products accumulated in fp32 on the bf16 MFMA pipe
+ * (csrc/wino_split.hip.inc); its error against a float64 network is at or below the fp32 form's on every bi-TAI layer
+ * (profiles/r04_split_bf16_study.txt).  The mode decides what tai_conv3x3_wino_weight_floats / _transform_weights produce (mode 1:
+ * the fp32 image followed by the split image); the forward entry points follow the buffer they are handed, so a buffer is always
+ * read in the layout it was written in, and layers the split kernel does not take (displaced reads, tile rows that are neither a
+ * power of two nor a multiple of 16 tiles) run the fp32 kernel from the same buffer.  Returns the previous mode, negative on a bad
+ * argument. */
+int tai_conv3x3_wino_set_arithmetic(int mode);
+int tai_conv3x3_wino_get_arithmetic(void);
 /* Benchmarking: 0 keeps every layer on the 64-channel x 64-tile workgroup shape; 1 (default) lets layers whose K is a
  * multiple of 128 use the 128 x 32 shape.  Returns the previous value. */
 int tai_conv3x3_wino_set_tall(int on);

@@ -163,6 +163,10 @@ def lib():
     L.tai_conv_cin1_forward_maxpool_window.argtypes = [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, V]
     L.tai_conv_cin1_forward_maxpool_window.restype = I
     L.tai_conv3x3_wino_set_tall.argtypes = [I]
+    L.tai_conv3x3_wino_set_arithmetic.argtypes = [I]
+    L.tai_conv3x3_wino_set_arithmetic.restype = I
+    L.tai_conv3x3_wino_get_arithmetic.argtypes = []
+    L.tai_conv3x3_wino_get_arithmetic.restype = I
     L.tai_conv3x3_wino_set_tall.restype = I
     L.tai_conv3x3_wino_forward_parts.argtypes = [P, I, P, P, P, I, I, I, I, I, I, V]
     L.tai_conv3x3_wino_forward_parts.restype = I

@@ -43,6 +43,29 @@ def invalidate_derived(module=None):
             p._tai_derived.clear()
 
 
+WINOGRAD_ARITHMETICS = {'fp32': 0, 'bf16x3': 1}
+
+
+def set_winograd_arithmetic(name):
+    """Arithmetic of the Winograd 3x3 GEMMs (``tai_conv3x3_wino_set_arithmetic``): ``'fp32'`` (default: the fp32 MFMA, the
+    reference's arithmetic class and the one every parity statement is made on) or ``'bf16x3'`` (opt-in: every fp32 operand
+    as three bf16 terms, six bf16 products per product, fp32 accumulation -- csrc/wino_split.hip.inc).  Cached transformed
+    weights are rebuilt in the new layout; a hipGraph captured before the switch keeps replaying the arithmetic it was
+    captured with.  Returns the previous name."""
+    mode = WINOGRAD_ARITHMETICS[name]
+    prev = _native.lib().tai_conv3x3_wino_set_arithmetic(mode)
+    if prev < 0:
+        raise ValueError(name)
+    if prev != mode:
+        invalidate_derived()
+    return [k for k, v in WINOGRAD_ARITHMETICS.items() if v == prev][0]
+
+
+def get_winograd_arithmetic():
+    mode = _native.lib().tai_conv3x3_wino_get_arithmetic()
+    return [k for k, v in WINOGRAD_ARITHMETICS.items() if v == mode][0]
+
+
 def _cached(weight, tag, make):
     """Derived form of a weight, kept on the tensor object and rebuilt when the weight's version counter or storage
     moves, or after ``invalidate_derived``."""

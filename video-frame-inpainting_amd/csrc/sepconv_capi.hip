@@ -10,6 +10,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <unordered_set>
 
 #include "tai_sepconv.h"
 
@@ -19,6 +21,7 @@
 #include "bias_act.hip.inc"
 #include "thin_conv.hip.inc"
 #include "wino_conv.hip.inc"
+#include "wino_split.hip.inc"
 #include "wino_wrw.hip.inc"
 #include "spectral_norm.hip.inc"
 #include "hbm_probe.hip.inc"
@@ -604,10 +607,26 @@ int tai_conv_cout1_5x5_forward(const float* x, const float* weight, const float*
     return check_launch("conv_cout1_5x5");
 }
 
+// Arithmetic of the Winograd GEMMs: 0 = fp32 MFMA (the default; every parity claim), 1 = split bf16 (three terms, six products,
+// fp32 accumulation: wino_split.hip.inc), opt-in.  The mode decides what tai_conv3x3_wino_weight_floats / _transform_weights
+// produce: in mode 1 the buffer holds the fp32 image FOLLOWED by the split image, and the buffer is remembered, so that the forward
+// entry points follow the BUFFER they are handed (a shape the split kernel does not take runs the fp32 kernel on the same buffer)
+// and a buffer made in one mode can never be read in the other's layout.
+static std::atomic<int> g_wino_arith{0};
+static std::mutex g_split_mu;
+static std::unordered_set<const void*> g_split_bufs;
+int tai_conv3x3_wino_set_arithmetic(int mode) {
+    g_err[0] = 0;
+    if (mode != 0 && mode != 1) return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_set_arithmetic: 0 (fp32 MFMA) or 1 (split bf16)");
+    return g_wino_arith.exchange(mode, std::memory_order_relaxed);
+}
+int tai_conv3x3_wino_get_arithmetic(void) { return g_wino_arith.load(std::memory_order_relaxed); }
+
 long long tai_conv3x3_wino_weight_floats(int K, int C) {
     if (K <= 0 || C <= 0) return 0;
     const long long Kpad = (K + wino::TM - 1) / wino::TM * wino::TM, Cpad = (C + wino::KC - 1) / wino::KC * wino::KC;
-    return 16 * Kpad * Cpad;
+    // (split image: 16 positions x 3 bf16 terms per weight = 24 floats' worth)
+    return (g_wino_arith.load(std::memory_order_relaxed) == 1 ? 40 : 16) * Kpad * Cpad;
 }
 
 int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int C, void* hip_stream) {
@@ -616,8 +635,16 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
     const int Kpad = (K + wino::TM - 1) / wino::TM * wino::TM, Cpad = (C + wino::KC - 1) / wino::KC * wino::KC;
     const long long total = (long long)Kpad * Cpad;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const bool split = g_wino_arith.load(std::memory_order_relaxed) == 1;
+    {
+        std::lock_guard<std::mutex> lk(g_split_mu);
+        if (split) g_split_bufs.insert(U); else g_split_bufs.erase(U);
+    }
     hipLaunchKernelGGL(wino::transform_weights, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), weight, U, K,
                        C, Kpad, Cpad);
+    if (split)
+        hipLaunchKernelGGL(wino::split::transform_weights, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), weight,
+                           reinterpret_cast<unsigned short*>(U + 16 * total), K, C, Kpad, Cpad);
     return check_launch("wino_transform_weights");
 }
 
@@ -826,6 +853,52 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
     const long long tiles = (long long)N * (H / 2) * (W / 2);
     const long long tblocks = (tiles + wino::TN - 1) / wino::TN;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    // A buffer made in split arithmetic (tai_conv3x3_wino_set_arithmetic(1)) takes the split-bf16 kernel where that kernel has the
+    // shape: no displaced reads, no timeline stamps, tile rows of 2^k or 16 m tiles (its 16-lane neighbour shifts).
+    {
+        bool split_buf;
+        { std::lock_guard<std::mutex> lk(g_split_mu); split_buf = g_split_bufs.count(U) != 0; }
+        const int tw = W / 2;
+        const bool tw_ok = tw % 16 == 0 || (tw >= 2 && (tw & (tw - 1)) == 0);
+        const int epi_s = ex.addx ? (ex.y2 ? 1 : 2) : 0;
+        if (split_buf && !S && !stamps && tw_ok && !(epi_s && act != 0)) {
+            const unsigned short* U3 = reinterpret_cast<const unsigned short*>(U + 16LL * Kpad * Cpad);
+            const bool edge = tw > 16 || in_ox > 0 || in_w > W + in_ox;
+            wino::DivMagic dvS;
+            auto magic_s = [](long long d, unsigned& m, unsigned& sh) {
+                if (d <= 1) { m = 0; sh = 0; return; }
+                int lg = 0;
+                while ((2LL << lg) <= d) ++lg;
+                if ((1LL << lg) == d) --lg;
+                sh = (unsigned)lg;
+                const unsigned __int128 num = (unsigned __int128)1 << (32 + lg);
+                m = (unsigned)((num + (unsigned __int128)d - 1) / (unsigned __int128)d);
+            };
+            magic_s((long long)(H / 2) * (W / 2), dvS.m_tpi, dvS.s_tpi);
+            magic_s(W / 2, dvS.m_tw, dvS.s_tw);
+            magic_s(kblocks, dvS.m_kb, dvS.s_kb);
+            const int pm = nparts > 1 ? 1 : 0;
+#define TAI_LAUNCH_SPLIT(A, Q, E, G)                                                                                              \
+            do {                                                                                                                  \
+                auto kern = wino::split::conv3x3<A, Q, E, G>;                                                                     \
+                if (int rc = allow_lds(kern, wino::split::LDS_BYTES)) return rc;                                                  \
+                hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::split::LDS_BYTES, s, xs[0], xs[1], \
+                                   xs[2], xs[3], cpart, U3, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, nchunks,     \
+                                   kblocks, pool_h, pool_w, pool_oy, pool_ox, ex.addx, ex.y2, dvS, (long long*)nullptr);          \
+            } while (0)
+#define TAI_LAUNCH_SPLIT_G(A, Q, E) do { if (edge) TAI_LAUNCH_SPLIT(A, Q, E, true); else TAI_LAUNCH_SPLIT(A, Q, E, false); } while (0)
+#define TAI_LAUNCH_SPLIT_Q(A, E) do { if (pm) TAI_LAUNCH_SPLIT_G(A, 1, E); else TAI_LAUNCH_SPLIT_G(A, 0, E); } while (0)
+            if (epi_s == 1) TAI_LAUNCH_SPLIT_Q(0, 1);
+            else if (epi_s == 2) TAI_LAUNCH_SPLIT_Q(0, 2);
+            else if (act == 0) TAI_LAUNCH_SPLIT_Q(0, 0);
+            else if (act == 1) TAI_LAUNCH_SPLIT_Q(1, 0);
+            else TAI_LAUNCH_SPLIT_Q(2, 0);
+#undef TAI_LAUNCH_SPLIT_Q
+#undef TAI_LAUNCH_SPLIT_G
+#undef TAI_LAUNCH_SPLIT
+            return check_launch("conv3x3_wino_split");
+        }
+    }
     const bool tall = Kpad % wino::TTM == 0 && g_wino_tall.load(std::memory_order_relaxed) != 0;
     const int skip = g_wino_timeline_skip.load(std::memory_order_relaxed);
     (void)skip;
