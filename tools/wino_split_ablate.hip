@@ -1,7 +1,7 @@
 // Where does a chunk of the split-bf16 Winograd kernel (csrc/wino_split.hip.inc) spend its cycles?  Standalone (no torch): launches the
 // kernel's DBG build -- wave 0 of every workgroup stamps the shader clock at entry, after the prologue, after every chunk, at the
 // end -- in the full form and with parts of the chunk loop left out (SKIP bits: 1 no transform / split arithmetic, 2 no LDS writes
-// of the patches, 4 no operand reads, 8 no weight DMA, 16 no patch loads, 32 no phase barriers, 64 no MFMAs; results are then wrong,
+// of the patches, 4 no operand reads, 8 no weight DMA, 16 no patch loads, 32 no barriers in the chunk loop, 64 no MFMAs; results are then wrong,
 // only the timing means something).  Per variant: kernel time by HIP events and the median over workgroups of the prologue, the
 // median chunk and the epilogue in shader cycles.
 // Build: hipcc -O3 -std=c++17 -fno-slp-vectorize -w --offload-arch=gfx950 tools/wino_split_ablate.hip -o build/wino_split_ablate
@@ -45,7 +45,7 @@ static void run(const Problem& p, const char* what) {
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), wino::split::LDS_BYTES, 0, p.x, p.x, p.x, p.x, p.C, p.U3, p.bias, p.y, (float*)nullptr,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), wino::split::LDS_BYTES, 0, p.x, p.x, p.x, p.x, p.C, p.U3, p.bias, p.y, (float*)nullptr,
                            p.N, p.C, p.K, p.H, p.W, p.H, p.W, 0, 0, p.nchunks, p.kblocks, p.H / 2, p.W / 2, 0, 0, (const float*)nullptr,
                            (float*)nullptr, p.dv, p.stamps);
         CK(hipEventRecord(e1));

@@ -882,7 +882,7 @@ static int wino_forward_impl(const float* const* xs, int nparts, const float* U,
             do {                                                                                                                  \
                 auto kern = wino::split::conv3x3<A, Q, E, G>;                                                                     \
                 if (int rc = allow_lds(kern, wino::split::LDS_BYTES)) return rc;                                                  \
-                hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(256), wino::split::LDS_BYTES, s, xs[0], xs[1], \
+                hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(512), wino::split::LDS_BYTES, s, xs[0], xs[1], \
                                    xs[2], xs[3], cpart, U3, bias, y, ypool, N, C, K, H, W, in_h, in_w, in_oy, in_ox, nchunks,     \
                                    kblocks, pool_h, pool_w, pool_oy, pool_ox, ex.addx, ex.y2, dvS, (long long*)nullptr);          \
             } while (0)
