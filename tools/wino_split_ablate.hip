@@ -71,17 +71,19 @@ static void run(const Problem& p, const char* what) {
 template <bool EDGE>
 static void run_all(const Problem& p) {
     run<EDGE, 0>(p, "full kernel");
+    run<EDGE, 1024>(p, "teams in phase");
     run<EDGE, 1>(p, "no transform / split arithmetic");
-    run<EDGE, 2>(p, "no patch LDS writes");
     run<EDGE, 4>(p, "no operand reads");
     run<EDGE, 8>(p, "no weight DMA");
     run<EDGE, 16>(p, "no patch loads");
-    run<EDGE, 32>(p, "no phase barriers");
+    run<EDGE, 8 | 16>(p, "no weight DMA, no patch loads");
+    run<EDGE, 32>(p, "no barriers in the chunk loop");
+    run<EDGE, 128>(p, "no barrier in front of position 3");
+    run<EDGE, 256>(p, "no barrier in front of position 7");
+    run<EDGE, 512>(p, "barriers without their lgkmcnt(0)");
     run<EDGE, 64>(p, "no MFMAs");
     run<EDGE, 1 | 2 | 8 | 16>(p, "MFMAs + operand reads + barriers only");
-    run<EDGE, 1 | 2 | 4 | 8 | 16>(p, "MFMAs + barriers only");
     run<EDGE, 1 | 2 | 4 | 8 | 16 | 32>(p, "MFMAs only");
-    run<EDGE, 64 | 4>(p, "no MFMAs, no operand reads");
 }
 
 int main(int argc, char** argv) {
