@@ -142,3 +142,44 @@ def test_second_output_epilogue_loads_go_out_before_the_stores(device_asm, epi):
             assert len(loads) == 16 and stores, (name, len(loads))          # the 16 add values (the bias entered through accumulator block 5)
             assert max(loads) < min(stores), name                            # every load is issued before the first output store
     assert found == 2
+
+
+@pytest.mark.parametrize('edge,nl', [(0, 6), (1, 12)])
+@pytest.mark.parametrize('parts', [0, 1])
+def test_split_kernel_counted_waits_registers_and_mfma_count(device_asm, parts, edge, nl):
+    """The split-bf16 kernel (csrc/wino_split.hip.inc, conv3x3<ACT 1, PARTS, EPI 0, EDGE>): its weight DMA is awaited by a counted
+    s_waitcnt vmcnt(NL) in front of the barrier of position 7 (and of the prologue), which assumes exactly NL compiler-tracked
+    patch loads behind the last DMA; two waves per SIMD, so 128 + 128 registers and not one spill; 24 MFMAs per chunk body."""
+    prefix = '_ZN4wino5split7conv3x3ILi1ELi%dELi0ELb%dELi0ELi0EE' % (parts, edge)
+    found = 0
+    for name, lines in _kernel_bodies(device_asm, prefix):
+        found += 1
+        assert not any(re.search(r'\bscratch_(load|store)', l) for l in lines), name
+        assert sum(1 for l in lines if 'v_mfma_f32_32x32x16_bf16' in l) == 4 * 24, name     # chunk 0, the two loop bodies, the tail
+        assert not any('v_mfma_f32_32x32x2_f32' in l for l in lines), name
+        assert sum(1 for l in lines if 'global_load_lds_dwordx4' in l) == 6 + 4 * 6, name
+        behind, checked = None, 0
+        for n, l in enumerate(lines):
+            if 'global_load_lds_dwordx4' in l:
+                behind = 0
+            elif behind is not None and re.search(r'\bbuffer_load_dword', l):
+                behind += 1
+            m = re.search(r's_waitcnt vmcnt\((\d+)\)', l)
+            if m and behind is not None and any('s_barrier' in x for x in lines[n:n + 4]) and int(m.group(1)) > 0:
+                # correctness: the wait may leave in flight at most what was issued BEHIND the last DMA; the prologue's DMA is its
+                # oldest operation (patches of three chunks and the bias follow: 3 NL + 4 loads), the loop's wait is exact
+                if checked == 0:
+                    assert int(m.group(1)) == nl and behind == 3 * nl + 4, (name, n, m.group(1), behind)
+                elif checked == 4:
+                    # the trailing chunk: its patch loads (for a chunk that does not exist) are dead code and gone, its DMA fills a
+                    # stage nobody reads: the wait is vacuous there (the loop's end waits for vmcnt(0) before LDS is reused)
+                    assert int(m.group(1)) == nl and behind in (0, nl), (name, n, m.group(1), behind)
+                else:
+                    assert int(m.group(1)) == behind == nl, (name, n, m.group(1), behind)
+                checked += 1
+                behind = None
+        assert checked == 5, (name, checked)                      # prologue + four chunk bodies
+    assert found == 1
+    text = device_asm[device_asm.find(prefix):]
+    meta = text[text.find('.amdhsa_kernel'):text.find('.end_amdhsa_kernel')]
+    assert re.search(r'\.amdhsa_accum_offset\s+128', meta) and re.search(r'\.amdhsa_next_free_vgpr\s+256', meta), meta[:400]

@@ -28,6 +28,9 @@ def main(args=None):
     if getattr(opt, 'miopen_find_mode', None):          # before the first convolution reaches MIOpen
         os.environ['MIOPEN_FIND_MODE'] = opt.miopen_find_mode
     rank, world, local_rank = parallel.init_from_env()
+    if getattr(opt, 'winograd_arithmetic', 'fp32') != 'fp32':
+        from video_frame_inpainting_amd import conv_ops
+        conv_ops.set_winograd_arithmetic(opt.winograd_arithmetic)
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
     H, W = opt.image_size[0] + opt.padding_size[0], opt.image_size[1] + opt.padding_size[1]

@@ -31,6 +31,10 @@ class BaseOptions(object):
         g.add_argument('--synthetic', type=int, default=0, metavar='N_CLIPS',
                        help='(this build) run on N seeded synthetic clips instead of a video list')
         g.add_argument('--seed', type=int, default=1002, help='(this build) seed of the synthetic clips')
+        g.add_argument('--winograd_arithmetic', type=str, default='fp32', choices=['fp32', 'bf16x3'],
+                       help='(this build) arithmetic of the 3x3 Winograd GEMMs: fp32 = the fp32 MFMA (default, the arithmetic every '
+                            'parity statement is made on); bf16x3 = opt-in split bf16 (three bf16 terms per operand, six products, '
+                            'fp32 accumulation: error at or below the fp32 form, 3-25 %% faster per layer)')
 
     def parse(self, args=None, allow_unknown=False, require_gpu=True):
         if allow_unknown:
