@@ -10,9 +10,12 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
+#include <cstring>
 #include <vector>
 #include "../video-frame-inpainting_amd/csrc/wino_conv.hip.inc"
 #include "../video-frame-inpainting_amd/csrc/wino_split.hip.inc"
+#include "experiments/r04_split_producer_consumer.hip.inc"
 
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(_e), __LINE__); exit(1); } } while (0)
 
@@ -35,9 +38,14 @@ struct Problem {
     wino::DivMagic dv;
 };
 
-template <bool EDGE, int SKIP>
+static std::vector<float> g_ref;
+static bool g_pc = false;       // argv[6] == "pc": the producer / consumer form (12 waves)
+
+template <bool EDGE, int SKIP, bool PC = false>
 static void run(const Problem& p, const char* what) {
-    auto kern = wino::split::conv3x3<1, 0, 0, EDGE, 1, SKIP>;
+    if (g_pc && !PC) { run<EDGE, SKIP, true>(p, what); return; }
+    auto kern = PC ? wino::split::conv3x3_pc<1, 0, 0, EDGE, 1, SKIP> : wino::split::conv3x3<1, 0, 0, EDGE, 1, SKIP>;
+    const int threads = PC ? 768 : 512;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, wino::split::LDS_BYTES));
     const unsigned grid = (unsigned)(p.tblocks * p.kblocks);
     hipEvent_t e0, e1;
@@ -45,7 +53,7 @@ static void run(const Problem& p, const char* what) {
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), wino::split::LDS_BYTES, 0, p.x, p.x, p.x, p.x, p.C, p.U3, p.bias, p.y, (float*)nullptr,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), wino::split::LDS_BYTES, 0, p.x, p.x, p.x, p.x, p.C, p.U3, p.bias, p.y, (float*)nullptr,
                            p.N, p.C, p.K, p.H, p.W, p.H, p.W, 0, 0, p.nchunks, p.kblocks, p.H / 2, p.W / 2, 0, 0, (const float*)nullptr,
                            (float*)nullptr, p.dv, p.stamps);
         CK(hipEventRecord(e1));
@@ -63,6 +71,17 @@ static void run(const Problem& p, const char* what) {
         for (int c = 1; c < nst; ++c) chunk.push_back(s[4 + c] - s[4 + c - 1]);
     }
     auto med = [](std::vector<long long>& v) { if (v.empty()) return 0LL; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    if (SKIP == 0) {          // the two forms must agree bit for bit: keep the first full run's output, compare the later ones
+        std::vector<float>& ref = g_ref;
+        std::vector<float> out((size_t)p.N * p.K * p.H * p.W);
+        CK(hipMemcpy(out.data(), p.y, out.size() * 4, hipMemcpyDeviceToHost));
+        if (ref.empty()) ref = out;
+        else {
+            size_t bad = 0; double worst = 0;
+            for (size_t i = 0; i < out.size(); ++i) if (out[i] != ref[i]) { ++bad; worst = std::max(worst, (double)fabsf(out[i] - ref[i])); }
+            printf("  %s form against the first full run: %zu of %zu outputs differ (max %.3g)\n", PC ? "producer / consumer" : "two-team", bad, out.size(), worst);
+        }
+    }
     printf("  SKIP %3d %-44s %8.1f us   prologue %6lld  chunk %6lld  epilogue %6lld  workgroup %7lld cycles\n", SKIP, what, best * 1e3f,
            med(pro), med(chunk), med(epi), med(total));
     fflush(stdout);
@@ -114,6 +133,10 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     const bool edge = tw > 16;
     printf("x(%d,%d,%d,%d) -> %d: %lld workgroups, %d chunks, EDGE %d\n", p.N, p.C, p.H, p.W, p.K, p.tblocks * p.kblocks, p.nchunks, (int)edge);
+    if (argc >= 7 && !strcmp(argv[6], "pc")) {
+        if (edge) run<true, 0, false>(p, "two-team form (reference output)"); else run<false, 0, false>(p, "two-team form (reference output)");
+        g_pc = true;
+    }
     if (edge) run_all<true>(p); else run_all<false>(p);
     return 0;
 }
