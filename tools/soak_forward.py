@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the replayed bi-TAI forward (configs[1], the persistent sepconv kernel inside): N replays, every output compared bit for
 bit with the first replay's (the forward is deterministic: fixed summation orders everywhere).  A rare stale read behind the
-LDS-counter synchronisation would show as a mismatch; a hang as the watchdog of the caller.  Usage: python tools/soak_forward.py [N]"""
+LDS-counter synchronisation would show as a mismatch; a hang as the watchdog of the caller.  Usage: python tools/soak_forward.py [N] [intree] [color] [long] [split]"""
 import os
 import sys
 import time
@@ -15,6 +15,9 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 if len(sys.argv) > 2 and sys.argv[2] == 'intree':        # every 3x3 layer on the in-tree Winograd kernel (no MIOpen layer left)
     from video_frame_inpainting_amd import conv_ops
     conv_ops.WINO_MIN_WORKGROUPS = 0
+if 'split' in sys.argv[2:]:                 # the opt-in split-bf16 Winograd arithmetic (csrc/wino_split.hip.inc: eight waves, two barriers per chunk)
+    from video_frame_inpainting_amd import conv_ops
+    conv_ops.set_winograd_arithmetic('bf16x3')
 dev = torch.device('cuda:0')
 COLOR = 'color' in sys.argv[2:]              # configs[3]: TAI_color 256 x 256, 16 clips (three-channel sepconv kernel 19)
 LONG = 'long' in sys.argv[2:]                # configs[4]: T = 10 (640 tiles... 320 samples per sepconv launch: three rounds and more)
