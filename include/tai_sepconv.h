@@ -283,7 +283,8 @@ int tai_sepconv_set_grad_input_variant(int variant);
 /* grad_vertical / grad_horizontal kernels: 0 = automatic (one fused launch of the hand-scheduled wave types when C == 1
  * and both are requested; the gV waves' tap loads issued at kernel entry, the patch staged by the gH waves through LDS-DMA),
  * 1 = the two separate HIP kernels, 2 = the fused launch with the patch staged behind a workgroup barrier first (round 2's
- * form, A/B).  Returns the previous value. */
+ * form, A/B), 3 / 4 = as 0 with the gV waves at priority 0 / 2 instead of their gH partners' 1 (A/B; the results are the same
+ * bits).  Returns the previous value. */
 int tai_sepconv_set_grad_taps_variant(int variant);
 
 /* Algorithmic HBM bytes of one call: each operand read once, each result written once. */

@@ -124,7 +124,16 @@ def test_persistent_sepconv_kernel_polls_lds_and_keeps_its_loads_in_flight(devic
         pre = lines[:fold[0]]
         last_asm = max(n for n, l in enumerate(pre) if 'ASMSTART' in l)
         assert sum(1 for l in pre[last_asm:] if re.search(r'\bglobal_load_dwordx4\b', l)) == 11, name
-    assert found == 4              # <NT, REV> = <0, 0>, <0, 1>, <1, 0>, <1, 1>
+        # <1, 1, APRIO = 0 / 1 / 2>: the type-A row loop keeps ONE priority (1, its type-B partner's, in the form the launcher picks beyond
+        # the Infinity Cache); <..., -1>: kernel 16's alternation 2, 2, 0.  s_setprio 1 also opens every type-B row loop.
+        m = re.search(r'Lb1ELb1ELi(n?\d+)E', name)
+        if m and m.group(1) in ('0', '1', '2'):
+            assert not any(re.search(r'\bs_setprio 2\b', l) for l in lines) or m.group(1) == '2', name
+            want_prio = int(m.group(1))
+            assert sum(1 for l in lines if re.search(r'\bs_setprio %d\b' % want_prio, l)) >= 1, name
+        else:
+            assert sum(1 for l in lines if re.search(r'\bs_setprio 2\b', l)) >= 4, name
+    assert found == 7              # <NT, REV, APRIO> = <0, 0>, <0, 1>, <1, 0>, <1, 1> at -1 and <1, 1> at 0, 1, 2
 
 
 @pytest.mark.parametrize('epi', [1, 2])

@@ -25,6 +25,7 @@ Tap pairing (see sepconv_forward_packed): even pixels pair taps (2i, 2i+1), odd 
 both multiply the aligned window pair W2[m] = (w[2m], w[2m+1]) with m = i + (p >> 1).
 """
 import os
+import re
 
 KS = 51
 PITCH_BYTES = 180 * 4
@@ -35,6 +36,10 @@ NBUF = 4                 # window buffers (LOOKAHEAD + 1)
 ABLATE_VMCNT = False     # timing experiments only: drop the v-ring wait / the window waits (results are then wrong)
 ABLATE_LGKM = False
 PRIO_ALTERNATE = False   # type A: s_setprio 2 on even rows, 0 on odd rows (its type-B SIMD partner sits at 1)
+PRIO_CONST = None        # type A at ONE priority for the whole row loop (0, 1 or 2; the *_P<n>_NT forms of the persistent kernel): with
+                         # the alternation above a type-A wave catches up with its type-B partner and both then fall into step -- in
+                         # their row loops together, in their memory phases together; a constant 0 lets the type-B wave (at 1) run
+                         # ahead, so that one wave of a SIMD computes while the other streams its taps
 NCHUNK = 14              # 13 x b128 + 1 x b64 = 27 window pairs
 NW2 = 27
 
@@ -119,11 +124,16 @@ def emit_chunk_fmas(lines, k, first_done, base=0):
                 first_done.add(p)
 
 
+PRIO_PATTERN = None      # type A: priorities of rows 3k, 3k + 1, 3k + 2 (the *_Q<abc>_NT forms; PRIO_ALTERNATE is the pattern (2, 2, 0))
+
+
 def emit_row(L, phase):
     base = NCHUNK * phase            # running chunk number of this row's chunk 0
     if PRIO_ALTERNATE:
         # the type-B partner sits at priority 1: this wave wins the SIMD's VALU arbitration on 2 rows out of 3
         L.append('s_setprio %d' % (0 if phase % 3 == 2 else 2))
+    elif PRIO_PATTERN is not None:
+        L.append('s_setprio %d' % PRIO_PATTERN[phase % 3])
     if not ABLATE_VMCNT:
         L.append('s_waitcnt vmcnt(%d)' % (RING - 1))
     L.append('v_add_u32 v%d, %s, v%d' % (V_TMP, S_SLOT_RD, V_RING))
@@ -178,6 +188,8 @@ def gen():
         L.append('s_addc_u32 %s, %s, 0' % (S_PTR_HI, S_PTR_HI))
     # s[64:65] now points at row RING
     L.append('s_mov_b32 %s, 0' % S_ROW)
+    if PRIO_CONST is not None:
+        L.append('s_setprio %d' % PRIO_CONST)
     L.append('s_mov_b32 %s, 0' % S_SLOT_RD)
     L.append('s_mov_b32 %s, %d' % (S_SLOT_WR, RING * 1024))
     for k in range(LOOKAHEAD):
@@ -188,7 +200,7 @@ def gen():
     # (phase 0 and phase 1) and the odd 51st row is emitted once more behind the loop.
     from math import gcd
     period = NBUF // gcd(NCHUNK, NBUF)          # rows after which the buffer rotation repeats
-    body_rows = period * 3 if PRIO_ALTERNATE else period
+    body_rows = period * 3 if (PRIO_ALTERNATE or PRIO_PATTERN is not None) else period
     n_loops = KS // body_rows
     for ph in range(body_rows):
         emit_row(L, ph)
@@ -198,7 +210,7 @@ def gen():
         emit_row(L, ph)
     # ---------------- drain: the three window reads issued for the (non-existent) next row, the DMA tail
     L.append('s_waitcnt vmcnt(0) lgkmcnt(0)')
-    if PRIO_ALTERNATE:
+    if PRIO_ALTERNATE or PRIO_CONST is not None or PRIO_PATTERN is not None:
         L.append('s_setprio 0')
     return L
 
@@ -367,8 +379,13 @@ def gen_fold():
     return L
 
 
+GV_PRIO = None          # gV waves at a constant priority (their gH partners, the forward's type B, sit at 1); None: left at 0
+
+
 def gen_gv():
     L = []
+    if GV_PRIO is not None:
+        L.append('s_setprio %d' % GV_PRIO)
     L.append('v_mov_b32 v%d, v%d' % (V_ROW, V_ROW_IN))
     L.append('s_mov_b32 %s, s60' % S_PTR_LO)
     L.append('s_mov_b32 %s, s61' % S_PTR_HI)
@@ -384,6 +401,8 @@ def gen_gv():
     L.append('s_cbranch_scc1 1b')
     emit_row_gv(L, 0)
     L.append('s_waitcnt vmcnt(0) lgkmcnt(0)')
+    if GV_PRIO is not None:
+        L.append('s_setprio 0')
     return L
 
 
@@ -649,8 +668,11 @@ def gen_gi():
     return L
 
 
+PATTERNS = ()             # measured and dropped (profiles/r04_sepconv_priority_ab.txt): '112', '122', '110', '102' -- all slower than a constant 1
+
+
 def main():
-    global LOOKAHEAD, NBUF, ABLATE_VMCNT, ABLATE_LGKM, PRIO_ALTERNATE, NT
+    global LOOKAHEAD, NBUF, ABLATE_VMCNT, ABLATE_LGKM, PRIO_ALTERNATE, PRIO_CONST, PRIO_PATTERN, NT
     here = os.path.dirname(os.path.abspath(__file__))
     out = os.path.join(here, '..', 'video-frame-inpainting_amd', 'csrc', 'sepconv_fwd_rowloop.inc')
     variants = [('TAI_FWD_ROWLOOP_ASM', 3, 4, False, False),
@@ -663,12 +685,22 @@ def main():
         f.write('#define TAI_FWD_ROWLOOP_RING_SLOTS %d\n' % SLOTS)
         variants.append(('TAI_FWD_ROWLOOP_ASM_PRIO', 3, 4, False, False))   # type A next to a type-B partner
         variants.append(('TAI_FWD_ROWLOOP_ASM_PRIO_NT', 3, 4, False, False))   # the same, v planes loaded non-temporally
+        for pc in (0, 1, 2):                                                    # type A at one constant priority (persistent kernel, nt route)
+            variants.append(('TAI_FWD_ROWLOOP_ASM_P%d_NT' % pc, 3, 4, False, False))
+        for pat in PATTERNS:                                                    # ... at a priority pattern over three rows
+            variants.append(('TAI_FWD_ROWLOOP_ASM_Q%s_NT' % pat, 3, 4, False, False))
         for name, la, nbuf, novm, nolgkm in variants:
             LOOKAHEAD, NBUF, ABLATE_VMCNT, ABLATE_LGKM = la, nbuf, novm, nolgkm
             PRIO_ALTERNATE = '_PRIO' in name
+            mpc = re.search(r'_P(\d)_NT$', name)
+            PRIO_CONST = int(mpc.group(1)) if mpc else None
+            mpq = re.search(r'_Q(\d\d\d)_NT$', name)
+            PRIO_PATTERN = tuple(int(c) for c in mpq.group(1)) if mpq else None
             NT = ' nt' if name.endswith('_NT') else ''
             lines = gen()
             NT = ''
+            PRIO_CONST = None
+            PRIO_PATTERN = None
             n_pk = sum(1 for l in lines if l.startswith('v_pk_'))
             f.write('// %s: ks=%d ring=%d slots=%d lookahead=%d buffers=%d; %d instructions, %d packed.\n'
                     % (name, KS, RING, SLOTS, LOOKAHEAD, NBUF, len(lines), n_pk))
@@ -686,12 +718,16 @@ def main():
             for l in lines:
                 f.write('    "%s\\n" \\\n' % l)
             f.write('    ""\n')
-        lines = gen_gv()
-        f.write('// TAI_GV_ROWLOOP_ASM (gV = gO * row sums, one store per row): %d instructions.\n' % len(lines))
-        f.write('#define TAI_GV_ROWLOOP_ASM \\\n')
-        for l in lines:
-            f.write('    "%s\\n" \\\n' % l)
-        f.write('    ""\n')
+        global GV_PRIO
+        for suffix, gvp in (('', None), ('_P1', 1), ('_P2', 2)):
+            GV_PRIO = gvp
+            lines = gen_gv()
+            GV_PRIO = None
+            f.write('// TAI_GV_ROWLOOP_ASM%s (gV = gO * row sums, one store per row): %d instructions.\n' % (suffix, len(lines)))
+            f.write('#define TAI_GV_ROWLOOP_ASM%s \\\n' % suffix)
+            for l in lines:
+                f.write('    "%s\\n" \\\n' % l)
+            f.write('    ""\n')
         for suffix in ('', '_NT'):
             NT = ' nt' if suffix else ''
             lines = gen_fold()

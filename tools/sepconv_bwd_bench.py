@@ -42,7 +42,7 @@ def timed(gi, gv, gh, per_graph=20, replays=5):
     return e0.elapsed_time(e1) * 1e3 / (per_graph * replays)
 
 
-for tv, name in ((2, 'patch staged behind a barrier, then the tap loads (round 2)'), (0, 'tap loads at entry, patch by LDS-DMA (default)'), (2, 'again'), (0, 'again')):
+for tv, name in ((2, 'patch staged behind a barrier, then the tap loads (round 2)'), (3, 'tap loads at entry, patch by LDS-DMA, gV waves at priority 0 (round 3)'), (0, 'the same with the gV waves at priority 1 (default)'), (4, 'the same with the gV waves at priority 2'), (2, 'again'), (3, 'again'), (0, 'again'), (4, 'again')):
     prev = L.tai_sepconv_set_grad_taps_variant(tv)
     taps = timed(None, gV, gH)
     L.tai_sepconv_set_grad_taps_variant(prev)

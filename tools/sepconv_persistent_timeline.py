@@ -13,6 +13,7 @@ from video_frame_inpainting_amd import _native, conv_ops
 dev = torch.device('cuda:0')
 L = _native.lib()
 KS, H, W, B = 51, 128, 128, 160
+VARIANT = int(sys.argv[1]) if len(sys.argv) > 1 else 120        # 120: the shipped scheme (= 126 beyond the Infinity Cache); 123: type A alternating 2, 2, 0; 125 / 126 / 127: type A at constant priority 0 / 1 / 2
 
 
 def sep(inp, v, h, out, variant):
@@ -32,14 +33,14 @@ w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(dev)
 b = torch.zeros(256, device=dev)
 with torch.no_grad():
     for _ in range(3):
-        conv_ops.conv_bias_act(x, w, b, 1, 'relu'); sep(inp, v, h, out, 120)
+        conv_ops.conv_bias_act(x, w, b, 1, 'relu'); sep(inp, v, h, out, VARIANT)
     torch.cuda.synchronize()
     for name, nconv in (('behind 30 convolutions (10 ms of MFMA)', 30), ('from idle', 0)):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             for _ in range(nconv):
                 conv_ops.conv_bias_act(x, w, b, 1, 'relu')
-            sep(inp, v, h, out, 120)
+            sep(inp, v, h, out, VARIANT)
         for _ in range(3):
             graph.replay()
         torch.cuda.synchronize()

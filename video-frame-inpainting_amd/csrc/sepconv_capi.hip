@@ -175,14 +175,17 @@ int fwd_persistent(const float* in, const float* v, const float* h, float* out, 
     if (grid > ntiles) grid = ntiles;
     const size_t patch = ((size_t)(16 + 50) * 180 * sizeof(float) + 1023) & ~(size_t)1023;
     const size_t lds = 2 * patch + (size_t)8 * TAI_FWD_ROWLOOP_RING_SLOTS * 1024 + 16;
-    if (policy == 0) policy = (2LL * B * 51 * H * W * 4 > (256LL << 20)) ? 3 : 1;
-#define TAI_LAUNCH_PERSISTENT(NT, REV)                                                                              \
+    if (policy == 0) policy = (2LL * B * 51 * H * W * 4 > (256LL << 20)) ? 6 : 1;
+#define TAI_LAUNCH_PERSISTENT(NT, REV, ...)                                                                         \
     {                                                                                                               \
-        auto kern = fwd::sepconv_forward_persistent<DBG, NT, REV>;                                                  \
+        auto kern = fwd::sepconv_forward_persistent<DBG, NT, REV __VA_OPT__(,) __VA_ARGS__>;                        \
         if (int rc = allow_lds(kern, lds)) return rc;                                                               \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, in, v, h, out, H, W, tiles_x, tiles_y, ntiles);     \
     }
-    if (policy == 3) TAI_LAUNCH_PERSISTENT(true, true)
+    if (policy == 5) TAI_LAUNCH_PERSISTENT(true, true, 0)
+    else if (policy == 6) TAI_LAUNCH_PERSISTENT(true, true, 1)
+    else if (policy == 7) TAI_LAUNCH_PERSISTENT(true, true, 2)
+    else if (policy == 3) TAI_LAUNCH_PERSISTENT(true, true)
     else if (policy == 4) TAI_LAUNCH_PERSISTENT(false, true)
     else if (policy == 2) TAI_LAUNCH_PERSISTENT(true, false)
     else TAI_LAUNCH_PERSISTENT(false, false)
@@ -275,7 +278,7 @@ int launch_grad_vh_tiled(const float* gO, const float* in, const float* v, const
 
 extern "C" {
 
-int tai_sepconv_version(void) { return 400; }     // 0.4.0: persistent forward kernel with nt tap loads + reversed walk beyond the Infinity Cache; source hash
+int tai_sepconv_version(void) { return 410; }     // 0.4.1: persistent forward kernel beyond the Infinity Cache: type-A waves at their partners' priority (0.4.0: nt tap loads + reversed walk; source hash)
 
 const char* tai_sepconv_last_error(void) { return g_err; }
 
@@ -351,6 +354,9 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 22: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 2);   // A/B: nt tap loads, forward walk
         case 23: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 3);   // A/B: nt tap loads, reversed walk
         case 24: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 4);   // A/B: default cache policy, reversed walk
+        case 25: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 5);   // A/B: as 23, type A at constant priority 0
+        case 26: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 6);   // A/B: as 23, type A at constant priority 1
+        case 27: return fwd_persistent(input, vertical, horizontal, output, B, C, H, W, s, true, 7);   // A/B: as 23, type A at constant priority 2
 #ifdef TAI_TIMING_VARIANTS   // timing experiments (wrong results by design): tools/ build only, never in the shipped library
         case 117: return fwd_asm_three_channels<true, 1>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 19 without the v-ring wait
         case 118: return fwd_asm_three_channels<true, 2>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 19 without the window waits
@@ -358,6 +364,10 @@ int tai_sepconv_forward(const float* input, const float* vertical, const float* 
         case 109: return fwd_ab_all_channels<4, 3>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 16 with stamps
         case 110: return fwd_ab_all_channels<5, 3>(input, vertical, horizontal, output, B, C, H, W, s);   // kernel 18 with stamps
         case 120: return fwd_persistent<1>(input, vertical, horizontal, output, B, C, H, W, s, true);    // kernel 20 with stamps
+        case 123: return fwd_persistent<1>(input, vertical, horizontal, output, B, C, H, W, s, true, 3);  // 23 (round 4's first scheme) with stamps
+        case 125: return fwd_persistent<1>(input, vertical, horizontal, output, B, C, H, W, s, true, 5);  // 25 / 26 / 27 with stamps
+        case 126: return fwd_persistent<1>(input, vertical, horizontal, output, B, C, H, W, s, true, 6);
+        case 127: return fwd_persistent<1>(input, vertical, horizontal, output, B, C, H, W, s, true, 7);
         case 106: return fwd_ab_all_channels<0, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 107: return fwd_ab_all_channels<2, 3>(input, vertical, horizontal, output, B, C, H, W, s);
         case 111: return fwd_asm_all_channels<false, 0, 8, 2>(input, vertical, horizontal, output, B, C, H, W, s);
@@ -1079,8 +1089,18 @@ int tai_sepconv_backward(const float* grad_output, const float* input, const flo
             if (int rc = allow_lds(kern, lds)) return rc;
             hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(512), lds, s, grad_output, input, vertical, horizontal,
                                grad_vertical, grad_horizontal, H, W, tiles_x, tiles_y);
-        } else {
-            auto kern = bwd::sepconv_grad_vh_ab<true>;
+        } else if (g_vh_variant.load(std::memory_order_relaxed) == 3) {       // A/B: gV waves left at priority 0 (the default until round 4)
+            auto kern = bwd::sepconv_grad_vh_ab<true, 0>;
+            if (int rc = allow_lds(kern, lds)) return rc;
+            hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(512), lds, s, grad_output, input, vertical, horizontal,
+                               grad_vertical, grad_horizontal, H, W, tiles_x, tiles_y);
+        } else if (g_vh_variant.load(std::memory_order_relaxed) == 4) {       // A/B: gV waves at priority 2
+            auto kern = bwd::sepconv_grad_vh_ab<true, 2>;
+            if (int rc = allow_lds(kern, lds)) return rc;
+            hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(512), lds, s, grad_output, input, vertical, horizontal,
+                               grad_vertical, grad_horizontal, H, W, tiles_x, tiles_y);
+        } else {        // gV waves at their gH partners' priority: 112-114 -> 109.6 us at [32,1,128,128], 490 -> 487 at [160,...] (same process)
+            auto kern = bwd::sepconv_grad_vh_ab<true, 1>;
             if (int rc = allow_lds(kern, lds)) return rc;
             hipLaunchKernelGGL(kern, dim3(B * tiles_x * tiles_y), dim3(512), lds, s, grad_output, input, vertical, horizontal,
                                grad_vertical, grad_horizontal, H, W, tiles_x, tiles_y);
