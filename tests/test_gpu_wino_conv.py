@@ -491,3 +491,48 @@ def test_wino_weight_gradient_reads_a_haloed_plane_like_the_padded_tensor():
     wd = torch.zeros(16, 16, 3, 3, dtype=torch.float64, device='cuda', requires_grad=True)
     ref = torch.autograd.grad(F.conv2d(plane.double()[:, :, :, 1:-1], wd, None), wd, go.double())[0]     # valid convolution over the framed plane
     assert float((got.double() - ref).abs().max()) <= 2e-4
+
+
+@pytest.mark.parametrize('nparts,cp,co,act,transposed', [(2, 64, 64, 'relu', False), (4, 32, 128, None, False), (2, 64, 64, None, True),
+                                                          (3, 24, 64, 'tanh', False)])
+def test_training_form_on_channel_parts_matches_the_concatenating_path_and_fp64(nparts, cp, co, act, transposed, monkeypatch):
+    """conv_ops._WinoConv3x3Parts (training: a tuple of channel parts read where they lie, one contiguous input gradient per part,
+    weight gradient per part) against the path that concatenates first (_WinoConv3x3) and against autograd of an fp64 conv2d.
+    Reference: conv(cat(...)) of Residual / CombLayers / ConvLstmCell, src/models/mcnet/mcnet.py:131-176,271-293."""
+    from video_frame_inpainting_amd import conv_ops
+    g = torch.Generator().manual_seed(nparts * 100 + cp)
+    N, H, W = 8, 64, 64
+    ci = nparts * cp
+    parts0 = [torch.randn(N, cp, H, W, generator=g).cuda() for _ in range(nparts)]
+    wshape = (ci, co, 3, 3) if transposed else (co, ci, 3, 3)
+    w0 = (torch.randn(*wshape, generator=g) * (2.0 / (9 * ci)) ** 0.5).cuda()
+    b0 = torch.randn(co, generator=g).cuda()
+    go = torch.randn(N, co, H, W, generator=g).cuda()
+
+    def run(parts_path):
+        monkeypatch.setattr(conv_ops, 'PARTS_UNDER_AUTOGRAD', parts_path)
+        parts = [p.clone().requires_grad_() for p in parts0]
+        w, b = w0.clone().requires_grad_(), b0.clone().requires_grad_()
+        y = conv_ops.conv_bias_act(tuple(parts), w, b, 1, act, transposed=transposed)
+        y.backward(go)
+        return y.detach(), [p.grad for p in parts], w.grad, b.grad
+
+    y1, gp1, gw1, gb1 = run(True)
+    y0, gp0, gw0, gb0 = run(False)
+    assert torch.equal(y1, y0)                                         # the parts kernel: the same bits as the concatenation
+    for a, c in zip(gp1, gp0):
+        assert a.is_contiguous() and torch.equal(a, c)                 # K-slices of the same input-gradient convolution
+    assert float((gw1 - gw0).abs().max()) <= 2e-5 * float(gw0.abs().max())     # per-part partial sums are grouped differently
+    assert float((gb1 - gb0).abs().max()) <= 2e-5 * float(gb0.abs().max())
+    # fp64 autograd of the reference form
+    parts = [p.double().requires_grad_() for p in parts0]
+    w, b = w0.double().requires_grad_(), b0.double().requires_grad_()
+    wc = w.transpose(0, 1).flip(2, 3) if transposed else w
+    y = F.conv2d(torch.cat(parts, 1), wc, b, padding=1)
+    y = torch.relu(y) if act == 'relu' else (torch.tanh(y) if act == 'tanh' else y)
+    y.backward(go.double())
+    assert float((y1.double() - y.detach()).abs().max()) <= 2e-5 * float(y.detach().abs().max())
+    for a, c in zip(gp1, parts):
+        assert float((a.double() - c.grad).abs().max()) <= 2e-5 * float(c.grad.abs().max())
+    assert float((gw1.double() - w.grad).abs().max()) <= 5e-5 * float(w.grad.abs().max())
+    assert float((gb1.double() - b.grad).abs().max()) <= 5e-5 * float(b.grad.abs().max())

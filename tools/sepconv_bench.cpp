@@ -39,7 +39,7 @@ static int check(int B, int C, int H, int W) {
     sepconv_oracle_forward_f64(in.data(), v.data(), h.data(), ref.data(), B, C, H, W, ks);
     float *din = up(in), *dv = up(v), *dh = up(h), *dgo = up(gO), *dout; CK(hipMalloc(&dout, out.size() * 4));
     int bad = 0;
-    for (int var = 1; var <= 20; ++var) {
+    for (int var = 1; var <= 27; ++var) {
         CK(hipMemset(dout, 0xff, out.size() * 4));
         tai_sepconv_set_forward_variant(var);
         int rc = tai_sepconv_forward(din, dv, dh, dout, B, C, H, W, ks, nullptr);
@@ -79,7 +79,7 @@ static void timeit(int B, int C, int H, int W, int iters) {
     CK(hipMalloc(&dout, (size_t)B * C * H * W * 4)); CK(hipMalloc(&dgI, in.size() * 4)); CK(hipMalloc(&dgV, v.size() * 4)); CK(hipMalloc(&dgH, h.size() * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double fb = (double)tai_sepconv_forward_bytes(B, C, H, W, ks), bb = (double)tai_sepconv_backward_bytes(B, C, H, W, ks);
-    for (int var = 1; var <= 20; ++var) {
+    for (int var = 1; var <= 27; ++var) {
         if (!want(var)) continue;
         tai_sepconv_set_forward_variant(var);
         const int n = var == 1 ? std::max(2, iters / 10) : iters;

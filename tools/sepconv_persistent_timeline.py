@@ -35,7 +35,8 @@ with torch.no_grad():
     for _ in range(3):
         conv_ops.conv_bias_act(x, w, b, 1, 'relu'); sep(inp, v, h, out, VARIANT)
     torch.cuda.synchronize()
-    for name, nconv in (('behind 30 convolutions (10 ms of MFMA)', 30), ('from idle', 0)):
+    NCONV = int(sys.argv[2]) if len(sys.argv) > 2 else 30     # ~0.33 ms of fp32 MFMA each
+    for name, nconv in (('behind %d convolutions (%.0f ms of MFMA)' % (NCONV, NCONV / 3.0), NCONV), ('from idle', 0)):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             for _ in range(nconv):

@@ -276,6 +276,10 @@ def _kxk_ok(N, Ci, Co, H, W, kh, kw, padding):
 # differed by 1.5e-6 from replay to replay; without it 1,500 replays of the whole forward are bit-identical (tools/soak_forward.py).
 WINO_MIN_WORKGROUPS = 72
 
+# Training: convolutions of a tuple of channel parts go through _WinoConv3x3Parts (no torch.cat in the forward, one contiguous input
+# gradient per part); False restores the concatenating path (A/B, tests)
+PARTS_UNDER_AUTOGRAD = True
+
 
 def _wino_ok(N, Ci, Co, H, W, kh, kw, padding, min_ci=8):
     """``min_ci``: the kernel pads the input channels to a multiple of 8 with zero weights, so fewer than 8 work -- at the cost of a
@@ -411,6 +415,91 @@ class _WinoConv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[2] and gb is None:
             gb = g.sum((0, 2, 3))
         return gx, gw, gb, None, None
+
+
+class _WinoConv3x3Parts(torch.autograd.Function):
+    """``_WinoConv3x3`` on an input given as up to four equal channel parts (the operands of a ``torch.cat`` along the channels that is
+    never materialised: Residual, CombLayers, the ConvLSTM's (input, h), the kernel network's 1024-channel input).  Under autograd the
+    parts used to be concatenated first (one copy of the layer's whole input per call) and the input gradient came back as ONE tensor,
+    whose channel slices every producer then had to copy into contiguous memory for its own backward.  Here the forward reads the parts
+    where they lie (``tai_conv3x3_wino_forward_parts``: the same bits as the convolution of the concatenation), the input gradient of
+    part i is its own launch of the Winograd kernel over the K-slice of the transposed, flipped weight that belongs to it (the layer's
+    work split by output channels: no flop more, a contiguous result per part) and the weight gradient is taken per part and joined
+    along the input channels (a [Co, Ci, 3, 3] copy)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, act, transposed, *parts):
+        x0 = parts[0]
+        Co, Ci = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
+        N, Cp, H, W = x0.shape
+        L = _native.lib()
+        U = _wino_weights(weight, transposed)
+        y = torch.empty((N, Co, H, W), dtype=x0.dtype, device=x0.device)
+        ptrs = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+        with torch.cuda.device(x0.device):
+            _native.check(L.tai_conv3x3_wino_forward_parts(ptrs, len(parts), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci, Co, H, W,
+                                                           _ACT[act], torch.cuda.current_stream(x0.device).cuda_stream),
+                          'tai_conv3x3_wino_forward_parts')
+        ctx.act, ctx.transposed, ctx.nparts = act, transposed, len(parts)
+        ctx.save_for_backward(weight, y if act is not None else None, *parts)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        saved = ctx.saved_tensors
+        weight, y, parts = saved[0], saved[1], saved[2:]
+        g = grad_out.contiguous()
+        if ctx.act == 'relu':
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        elif ctx.act == 'tanh':
+            g = torch.ops.aten.tanh_backward(g, y)
+        N, Cp, H, W = parts[0].shape
+        Co, n = g.shape[1], ctx.nparts
+        gparts = [None] * n
+        for i in range(n):
+            if ctx.needs_input_grad[4 + i]:
+                gparts[i] = _wino_launch(g, _wino_weights_input_grad_part(weight, ctx.transposed, i, n), _zero_bias(Cp, g.device),
+                                         N, Co, Cp, H, W, None)
+        gw = gb = None
+        if ctx.needs_input_grad[0]:
+            want_bias = ctx.needs_input_grad[1]
+            pieces = []
+            for i in range(n):
+                r = wino_weight_grad(parts[i], g, with_bias=(want_bias and i == 0))
+                if r is None:
+                    pieces = None
+                    break
+                if want_bias and i == 0:
+                    r, gb = r
+                pieces.append(r)
+            if pieces is None:                                        # shapes the Winograd weight-gradient kernel does not take
+                w_eff = _as_conv_weight(weight, ctx.transposed)
+                gw_eff = torch.ops.aten.convolution_backward(g, torch.cat(parts, dim=1), w_eff, [Co], [1, 1], [1, 1], [1, 1], False,
+                                                             [0, 0], 1, [False, True, False])[1]
+            else:
+                gw_eff = torch.cat(pieces, dim=1)
+            gw = _as_conv_weight(gw_eff, ctx.transposed)
+        if ctx.needs_input_grad[1] and gb is None:
+            gb = g.sum((0, 2, 3))
+        return (gw, gb, None, None) + tuple(gparts)
+
+
+def _wino_weights_input_grad_part(weight, transposed, i, nparts):
+    """Transformed weights of the input-gradient convolution of channel part ``i`` of ``nparts``: conv(g, w_i transposed and flipped)
+    with w_i the slice of the layer's effective weight [Co, Ci, 3, 3] over that part's input channels."""
+    def make():
+        w_eff = _as_conv_weight(weight.detach(), transposed)                              # [Co, Ci, 3, 3]
+        Cp = w_eff.shape[1] // nparts
+        w = w_eff[:, i * Cp:(i + 1) * Cp].transpose(0, 1).flip(2, 3).contiguous()          # [Cp, Co, 3, 3]
+        K, C = w.shape[0], w.shape[1]
+        L = _native.lib()
+        U = torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _native.check(L.tai_conv3x3_wino_transform_weights(w.data_ptr(), U.data_ptr(), K, C,
+                                                               torch.cuda.current_stream(w.device).cuda_stream),
+                          'tai_conv3x3_wino_transform_weights')
+        return U
+    return _cached(weight, ('wino_input_grad_part', transposed, i, nparts), make)
 
 
 class _WinoConvKxK(torch.autograd.Function):
@@ -663,6 +752,11 @@ def _conv_bias_act(x, weight, bias, padding, act, transposed, out):
                   and not (torch.is_grad_enabled() and (weight.requires_grad or bias.requires_grad or any(p.requires_grad for p in parts)))
                   and _wino_ok(N, Ci, Co, H, W, kh, kw, padding))
         if not direct:
+            if (len(parts) <= 4 and x0.is_cuda and x0.dtype == torch.float32 and bias is not None and Cp % 8 == 0 and Cp * len(parts) == Ci
+                    and kh == kw == 3 and all(p.shape == x0.shape and p.is_contiguous() and p.dtype == x0.dtype for p in parts)
+                    and torch.is_grad_enabled() and _wino_ok(N, Ci, Co, H, W, 3, 3, padding) and _wino_ok(N, Co, Cp, H, W, 3, 3, padding)
+                    and PARTS_UNDER_AUTOGRAD):
+                return _WinoConv3x3Parts.apply(weight, bias, act, transposed, *parts)     # training: the parts are read where they lie
             return _conv_bias_act(torch.cat(parts, dim=1), weight, bias, padding, act, transposed, out)
         L = _native.lib()
         U = _wino_weights(weight, transposed)

@@ -176,19 +176,19 @@ int fwd_persistent(const float* in, const float* v, const float* h, float* out, 
     const size_t patch = ((size_t)(16 + 50) * 180 * sizeof(float) + 1023) & ~(size_t)1023;
     const size_t lds = 2 * patch + (size_t)8 * TAI_FWD_ROWLOOP_RING_SLOTS * 1024 + 16;
     if (policy == 0) policy = (2LL * B * 51 * H * W * 4 > (256LL << 20)) ? 6 : 1;
-#define TAI_LAUNCH_PERSISTENT(NT, REV, ...)                                                                         \
+#define TAI_LAUNCH_PERSISTENT(NT, REV, APRIO)                                                                        \
     {                                                                                                               \
-        auto kern = fwd::sepconv_forward_persistent<DBG, NT, REV __VA_OPT__(,) __VA_ARGS__>;                        \
+        auto kern = fwd::sepconv_forward_persistent<DBG, NT, REV, APRIO>;                                           \
         if (int rc = allow_lds(kern, lds)) return rc;                                                               \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, in, v, h, out, H, W, tiles_x, tiles_y, ntiles);     \
     }
     if (policy == 5) TAI_LAUNCH_PERSISTENT(true, true, 0)
     else if (policy == 6) TAI_LAUNCH_PERSISTENT(true, true, 1)
     else if (policy == 7) TAI_LAUNCH_PERSISTENT(true, true, 2)
-    else if (policy == 3) TAI_LAUNCH_PERSISTENT(true, true)
-    else if (policy == 4) TAI_LAUNCH_PERSISTENT(false, true)
-    else if (policy == 2) TAI_LAUNCH_PERSISTENT(true, false)
-    else TAI_LAUNCH_PERSISTENT(false, false)
+    else if (policy == 3) TAI_LAUNCH_PERSISTENT(true, true, -1)
+    else if (policy == 4) TAI_LAUNCH_PERSISTENT(false, true, -1)
+    else if (policy == 2) TAI_LAUNCH_PERSISTENT(true, false, -1)
+    else TAI_LAUNCH_PERSISTENT(false, false, -1)
 #undef TAI_LAUNCH_PERSISTENT
     return check_launch("sepconv_forward_persistent");
 }
