@@ -73,7 +73,16 @@ def test_unpool2x_add_matches_the_strided_add():
         want = res.clone()
         want[:, :, 0::2, 0::2] += x
         assert torch.equal(got, want)
-    xr = torch.randn(1, 2, 4, 4, device='cuda', requires_grad=True)            # autograd keeps the PyTorch form
-    out = unpool2x_add(xr, torch.zeros(1, 2, 8, 8, device='cuda'))
-    out.sum().backward()
-    assert torch.equal(xr.grad, torch.ones_like(xr))
+    # under autograd: the same kernel (mcnet._Unpool2xAdd); gradients: identity for res, the even sites for x
+    xr = torch.randn(2, 3, 4, 6, generator=g).cuda().requires_grad_()
+    rr = torch.randn(2, 3, 8, 12, generator=g).cuda().requires_grad_()
+    go = torch.randn(2, 3, 8, 12, generator=g).cuda()
+    out = unpool2x_add(xr, rr)
+    want = rr.detach().clone()
+    want[:, :, 0::2, 0::2] += xr.detach()
+    assert torch.equal(out.detach(), want)
+    out.backward(go)
+    assert torch.equal(rr.grad, go) and torch.equal(xr.grad, go[:, :, 0::2, 0::2])
+    xr2 = torch.randn(1, 2, 4, 4, device='cuda', requires_grad=True)            # only x needs a gradient
+    unpool2x_add(xr2, torch.zeros(1, 2, 8, 8, device='cuda')).sum().backward()
+    assert torch.equal(xr2.grad, torch.ones_like(xr2))

@@ -73,9 +73,34 @@ def unpool2x_add(x, res):
                                                          x.shape[2], x.shape[3], torch.cuda.current_stream(x.device).cuda_stream),
                           'tai_unpool2x_add')
         return out
+    if (x.is_cuda and x.dtype == torch.float32 and res.dtype == torch.float32 and x.shape[3] % 2 == 0
+            and tuple(res.shape) == (x.shape[0], x.shape[1], 2 * x.shape[2], 2 * x.shape[3])):
+        return _Unpool2xAdd.apply(x, res)        # training: the same kernel under autograd
     out = res.clone()
     out[:, :, 0::2, 0::2] += x
     return out
+
+
+class _Unpool2xAdd(torch.autograd.Function):
+    """``fixed_unpooling(x) + res`` under autograd on ``tai_unpool2x_add``.  As ATen ops (clone, an in-place add on a strided slice)
+    the training path copied ``res`` once forwards and went through CopySlices backwards; here the forward is the one pass of the
+    inference path and the backward is the identity for ``res`` and a stride-2 gather for ``x``."""
+
+    @staticmethod
+    def forward(ctx, x, res):
+        from . import _native
+        x, res = x.contiguous(), res.contiguous()
+        out = torch.empty_like(res)
+        with torch.cuda.device(x.device):
+            _native.check(_native.lib().tai_unpool2x_add(x.data_ptr(), res.data_ptr(), out.data_ptr(), x.shape[0] * x.shape[1],
+                                                         x.shape[2], x.shape[3], torch.cuda.current_stream(x.device).cuda_stream),
+                          'tai_unpool2x_add')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = g[:, :, 0::2, 0::2].contiguous() if ctx.needs_input_grad[0] else None
+        return gx, (g if ctx.needs_input_grad[1] else None)
 
 
 class MotionEnc(nn.Module):
