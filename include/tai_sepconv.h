@@ -221,6 +221,15 @@ int tai_conv3x3_wino_forward_parts(const float* const* xs, int nparts, const flo
 int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_k, const float* U, const float* bias, float* y,
                                 float* ypool, int pool_h, int pool_w, int pool_oy, int pool_ox, const float* addx, float* y2, int N,
                                 int C, int K, int H, int W, int in_h, int in_w, int in_oy, int in_ox, int act, void* hip_stream);
+/* The same convolution as Winograd F(4x4, 3x3) on the fp32 MFMA pipe (csrc/wino43_conv.hip.inc): 36 multiplies per 4 x 4 output tile
+ * instead of 16 per 2 x 2 -- 1.78x fewer MFMAs, ~7x the fp32 rounding error per layer; opt-in, and meant for the layers with C >= 128
+ * and K >= 128, where the bi-TAI forward's end-to-end error is unchanged (profiles/r04_wino_f43_study.txt).  Own transformed-weight
+ * layout (tai_conv3x3_wino43_weight_floats / _transform_weights); H, W and C multiples of 4; act as above.  Replaces the same
+ * reference layers as tai_conv3x3_wino_forward (src/models/mcnet/mcnet.py:79-118,131-152,165-176,198-224). */
+long long tai_conv3x3_wino43_weight_floats(int K, int C);
+int tai_conv3x3_wino43_transform_weights(const float* weight, float* U, int K, int C, void* hip_stream);
+int tai_conv3x3_wino43_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W, int act,
+                               void* hip_stream);
 /* Arithmetic of the Winograd GEMMs, process-wide.  0 (default): fp32 MFMA -- the reference's arithmetic class (cuDNN fp32 behind
  * nn.Conv2d, src/models/mcnet/mcnet.py:28-224) and the one every parity statement of this library is made on.  1 (opt-in): SPLIT
  * bf16 -- each fp32 operand as three bf16 terms, a product as six bf16 products accumulated in fp32 on the bf16 MFMA pipe

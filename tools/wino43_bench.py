@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Winograd F(4x4, 3x3) prototype (csrc/wino43_conv.hip.inc) against the F(2x2, 3x3) kernel on the bi-TAI layers with C >= 128 and
+K >= 128: error against an fp64 convolution and time per call, same process, alternating.  Usage: python tools/wino43_bench.py [--quick]"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from video_frame_inpainting_amd import _native
+
+L = _native.lib()
+
+
+def make(which, x, w, b, act=1):
+    N, C, H, W = x.shape
+    K = w.shape[0]
+    s = torch.cuda.current_stream().cuda_stream
+    pre = 'tai_conv3x3_wino43' if which == 43 else 'tai_conv3x3_wino'
+    U = torch.empty(getattr(L, pre + '_weight_floats')(K, C), device='cuda')
+    _native.check(getattr(L, pre + '_transform_weights')(w.data_ptr(), U.data_ptr(), K, C, s), 'transform')
+    y = torch.full((N, K, H, W), float('nan'), device='cuda')
+    fwd = getattr(L, pre + '_forward')
+
+    def run():
+        _native.check(fwd(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), N, C, K, H, W, act, s), 'forward')
+        return y
+    return run
+
+
+def timed(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+quick = '--quick' in sys.argv
+shapes = [(1, 4, 64, 4, 4), (2, 8, 70, 12, 12), (3, 128, 128, 8, 20), (2, 12, 64, 16, 16)]
+if not quick:
+    shapes += [(64, 128, 128, 64, 64), (64, 256, 256, 32, 32), (64, 128, 256, 32, 32), (64, 512, 256, 32, 32), (64, 256, 128, 64, 64),
+               (64, 512, 1024, 16, 16), (160, 256, 256, 16, 16), (160, 512, 512, 8, 8)]
+for (N, C, K, H, W) in shapes:
+    g = torch.Generator().manual_seed(N + C + K)
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    w = (torch.randn(K, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** .5).cuda()
+    b = torch.randn(K, generator=g).cuda()
+    r43, r23 = make(43, x, w, b), make(23, x, w, b)
+    y43, y23 = r43().clone(), r23().clone()
+    if N * C * H * W <= 64 * 128 * 64 * 64:
+        ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+        mag = float(ref.abs().max())
+        e43, e23 = float((y43.double() - ref).abs().max()) / mag, float((y23.double() - ref).abs().max()) / mag
+    else:
+        e43, e23 = float((y43 - y23).abs().max()) / float(y23.abs().max()), float('nan')
+    assert torch.isfinite(y43).all()
+    t = [(timed(r23), timed(r43)) for _ in range(2)]
+    fl = 2.0 * N * K * C * 9 * H * W
+    print('x(%d,%d,%d,%d)->%d  F(2x2) %.0f / %.0f us (%.0f TF direct)   F(4x4) %.0f / %.0f us (%.0f TF)   ratio %.2fx | max err / max |ref|: F(4x4) %.2e  F(2x2) %.2e'
+          % (N, C, H, W, K, t[0][0], t[1][0], fl / t[1][0] / 1e6, t[0][1], t[1][1], fl / t[1][1] / 1e6, t[1][0] / t[1][1], e43, e23), flush=True)

@@ -153,6 +153,12 @@ def lib():
     L.tai_conv3x3_wino_transform_weights.argtypes = [P, P, I, I, V]
     L.tai_conv3x3_wino_transform_weights.restype = I
     L.tai_conv3x3_wino_forward.argtypes = [P, P, P, P, I, I, I, I, I, I, V]
+    L.tai_conv3x3_wino43_weight_floats.argtypes = [I, I]
+    L.tai_conv3x3_wino43_weight_floats.restype = ctypes.c_longlong
+    L.tai_conv3x3_wino43_transform_weights.argtypes = [P, P, I, I, V]
+    L.tai_conv3x3_wino43_transform_weights.restype = I
+    L.tai_conv3x3_wino43_forward.argtypes = [P, P, P, P, I, I, I, I, I, I, V]
+    L.tai_conv3x3_wino43_forward.restype = I
     L.tai_conv3x3_wino_forward.restype = I
     L.tai_conv3x3_wino_forward_maxpool.argtypes = [P, P, P, P, P, I, I, I, I, I, I, V]
     L.tai_conv3x3_wino_forward_maxpool.restype = I

@@ -22,6 +22,7 @@
 #include "thin_conv.hip.inc"
 #include "wino_conv.hip.inc"
 #include "wino_split.hip.inc"
+#include "wino43_conv.hip.inc"
 #include "wino_wrw.hip.inc"
 #include "spectral_norm.hip.inc"
 #include "hbm_probe.hip.inc"
@@ -656,6 +657,51 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
         hipLaunchKernelGGL(wino::split::transform_weights, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), weight,
                            reinterpret_cast<unsigned short*>(U + 16 * total), K, C, Kpad, Cpad);
     return check_launch("wino_transform_weights");
+}
+
+// ---- Winograd F(4x4, 3x3) on the fp32 MFMA pipe (csrc/wino43_conv.hip.inc): opt-in prototype -------------------------------------
+long long tai_conv3x3_wino43_weight_floats(int K, int C) {
+    if (K <= 0 || C <= 0 || C % wino43::KC != 0) return 0;
+    const long long Kpad = (K + wino43::TM - 1) / wino43::TM * wino43::TM;
+    return 36 * Kpad * C;
+}
+
+int tai_conv3x3_wino43_transform_weights(const float* weight, float* U, int K, int C, void* hip_stream) {
+    g_err[0] = 0;
+    if (!weight || !U || K <= 0 || C <= 0 || C % wino43::KC != 0)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "wino43 transform_weights: bad argument (C must be a multiple of 4)");
+    const int Kpad = (K + wino43::TM - 1) / wino43::TM * wino43::TM;
+    const long long total = (long long)Kpad * C;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wino43::transform_weights, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), weight, U, K, C,
+                       Kpad, C);
+    return check_launch("wino43_transform_weights");
+}
+
+int tai_conv3x3_wino43_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W, int act,
+                               void* hip_stream) {
+    g_err[0] = 0;
+    if (!x || !U || !bias || !y || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: bad argument");
+    if (H % 4 != 0 || W % 4 != 0 || C % wino43::KC != 0 || act < 0 || act > 2)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: needs H, W and C multiples of 4, act in {0, 1, 2}");
+    if ((long long)N * C * H * W >= (1LL << 29) || (long long)N * K * H * W >= (1LL << 29))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: tensor too large (2^29 elements or more)");
+    const int Kpad = (K + wino43::TM - 1) / wino43::TM * wino43::TM;
+    const int kblocks = Kpad / wino43::TM, nchunks = C / wino43::KC;
+    const long long tiles = (long long)N * (H / 4) * (W / 4);
+    const long long tblocks = (tiles + wino43::TN - 1) / wino43::TN;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+#define TAI_W43_LAUNCH(A)                                                                                                       \
+    {                                                                                                                           \
+        auto kern = wino43::conv3x3<A>;                                                                                         \
+        if (int rc = allow_lds(kern, wino43::LDS_BYTES)) return rc;                                                             \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(256), wino43::LDS_BYTES, s, x, U, bias, y, N, C, K, H, W, \
+                           Kpad, nchunks, kblocks);                                                                             \
+    }
+    if (act == 0) TAI_W43_LAUNCH(0) else if (act == 1) TAI_W43_LAUNCH(1) else TAI_W43_LAUNCH(2)
+#undef TAI_W43_LAUNCH
+    return check_launch("conv3x3_wino43");
 }
 
 // Split of the weight-gradient kernel's reduction (the tiles) over workgroups: about one workgroup per CU in total.
