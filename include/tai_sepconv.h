@@ -230,6 +230,10 @@ long long tai_conv3x3_wino43_weight_floats(int K, int C);
 int tai_conv3x3_wino43_transform_weights(const float* weight, float* U, int K, int C, void* hip_stream);
 int tai_conv3x3_wino43_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W, int act,
                                void* hip_stream);
+/* ... with the input given as 1 to 4 equal channel parts (contiguous [N, C / nparts, H, W] tensors; C / nparts a multiple of 4): the
+ * operands of a torch.cat along the channels that is never materialised (tai_conv3x3_wino_forward_parts' counterpart). */
+int tai_conv3x3_wino43_forward_parts(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C, int K,
+                                     int H, int W, int act, void* hip_stream);
 /* Arithmetic of the Winograd GEMMs, process-wide.  0 (default): fp32 MFMA -- the reference's arithmetic class (cuDNN fp32 behind
  * nn.Conv2d, src/models/mcnet/mcnet.py:28-224) and the one every parity statement of this library is made on.  1 (opt-in): SPLIT
  * bf16 -- each fp32 operand as three bf16 terms, a product as six bf16 products accumulated in fp32 on the bf16 MFMA pipe

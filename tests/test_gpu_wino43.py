@@ -1,0 +1,160 @@
+"""Winograd F(4x4, 3x3) on the fp32 MFMA pipe (csrc/wino43_conv.hip.inc; opt-in, conv_ops.set_winograd_tile(4)) against an fp64
+convolution of the same operands, against the F(2x2, 3x3) kernel, and -- the whole bi-TAI forward -- against the CPU oracle.
+Reference layers: nn.Conv2d(C, K, 3, padding=1) (+ReLU) of src/models/mcnet/mcnet.py:79-118,131-152,165-176,198-224 and
+src/models/tai/tai.py:248-286."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+_ACT = {None: 0, 'relu': 1, 'tanh': 2}
+# F(4x4, 3x3) in fp32: the transforms multiply by up to 8 (A^T), 5 (B^T) and 1/24 (G) before and after the products; against the
+# magnitude sum of a dot product its error is ~10x F(2x2, 3x3)'s (bound there: 4e-6, tests/test_gpu_wino_conv.py)
+TOL = 6e-5
+
+
+def _run(x_parts, w, b, act):
+    from video_frame_inpainting_amd import _native
+    L = _native.lib()
+    N, cp, H, W = x_parts[0].shape
+    C, K = cp * len(x_parts), w.shape[0]
+    s = torch.cuda.current_stream().cuda_stream
+    U = torch.empty(L.tai_conv3x3_wino43_weight_floats(K, C), device='cuda')
+    _native.check(L.tai_conv3x3_wino43_transform_weights(w.data_ptr(), U.data_ptr(), K, C, s), 'transform')
+    y = torch.full((N, K, H, W), float('nan'), device='cuda')
+    if len(x_parts) == 1:
+        _native.check(L.tai_conv3x3_wino43_forward(x_parts[0].data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), N, C, K, H, W, _ACT[act], s), 'forward')
+    else:
+        ptrs = (ctypes.c_void_p * len(x_parts))(*[p.data_ptr() for p in x_parts])
+        _native.check(L.tai_conv3x3_wino43_forward_parts(ptrs, len(x_parts), U.data_ptr(), b.data_ptr(), y.data_ptr(), N, C, K, H, W, _ACT[act], s),
+                      'forward_parts')
+    return y
+
+
+def _operands(N, C, K, H, W, seed=0):
+    g = torch.Generator().manual_seed(seed + N + C + K + H)
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    w = (torch.randn(K, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda()
+    b = torch.randn(K, generator=g).cuda()
+    return x, w, b
+
+
+# (N, C, K, H, W): one tile, tiles that straddle images and workgroups, K that is not a multiple of 64, C = 4, bi-TAI shapes
+SHAPES = [(1, 4, 64, 4, 4), (2, 8, 70, 12, 12), (3, 128, 128, 8, 20), (5, 12, 3, 4, 8), (2, 256, 256, 32, 32), (8, 512, 130, 16, 16),
+          (4, 128, 256, 64, 64)]
+
+
+@pytest.mark.parametrize('act', [None, 'relu', 'tanh'])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_wino43_matches_fp64_conv(shape, act):
+    x, w, b = _operands(*shape)
+    got = _run([x], w, b, act)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = torch.relu(ref) if act == 'relu' else (torch.tanh(ref) if act == 'tanh' else ref)
+    mag = F.conv2d(x.double().abs(), w.double().abs(), b.double().abs(), padding=1)
+    assert torch.isfinite(got).all()
+    err = float(((got.double() - ref).abs() / (1 + mag)).max())
+    assert err <= TOL, err
+
+
+def test_wino43_sees_every_tap_and_the_padding():
+    """One tap at a time on small-integer operands (G = 1/6, 1/24: unlike F(2x2, 3x3) the transformed weights are not exact in binary,
+    so the comparison has a bound: 1e-5 of the largest output), every pixel including the zero-padded border."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-2, 3, (2, 8, 8, 12), generator=g).float().cuda()
+    b = torch.randint(-3, 4, (64,), generator=g).float().cuda()
+    for ty in range(3):
+        for tx in range(3):
+            w = torch.zeros(64, 8, 3, 3)
+            w[:, :, ty, tx] = torch.randint(-1, 2, (64, 8), generator=g).float()
+            w = w.cuda()
+            want = F.conv2d(x, w, b, padding=1)
+            assert float((_run([x], w, b, None) - want).abs().max()) <= 1e-5 * float(want.abs().max()), (ty, tx)
+
+
+@pytest.mark.parametrize('nparts', [2, 4])
+def test_wino43_reads_channel_parts_without_a_cat(nparts):
+    N, cp, K, H, W = 3, 64, 128, 16, 24
+    g = torch.Generator().manual_seed(nparts)
+    parts = [torch.randn(N, cp, H, W, generator=g).cuda() for _ in range(nparts)]
+    w = (torch.randn(K, cp * nparts, 3, 3, generator=g) * 0.05).cuda()
+    b = torch.randn(K, generator=g).cuda()
+    assert torch.equal(_run(parts, w, b, 'relu'), _run([torch.cat(parts, 1)], w, b, 'relu'))
+
+
+def test_wino43_rejects_what_it_cannot_run():
+    from video_frame_inpainting_amd import _native
+    L = _native.lib()
+    x, w, b = _operands(1, 8, 64, 8, 8)
+    y = torch.empty(1, 64, 8, 8, device='cuda')
+    U = torch.empty(L.tai_conv3x3_wino43_weight_floats(64, 8), device='cuda')
+    s = torch.cuda.current_stream().cuda_stream
+    assert L.tai_conv3x3_wino43_weight_floats(64, 6) == 0                                                     # C % 4
+    assert L.tai_conv3x3_wino43_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 8, 64, 6, 8, 0, s) != 0      # H % 4
+    assert L.tai_conv3x3_wino43_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 6, 64, 8, 8, 0, s) != 0      # C % 4
+    assert L.tai_conv3x3_wino43_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 8, 64, 8, 8, 3, s) != 0      # act
+    assert L.tai_conv3x3_wino43_forward(None, U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 8, 64, 8, 8, 0, s) != 0
+
+
+def test_wino43_is_bit_reproducible():
+    x, w, b = _operands(8, 256, 256, 32, 32)
+    first = _run([x], w, b, 'relu').clone()
+    for _ in range(20):
+        assert torch.equal(_run([x], w, b, 'relu'), first)
+
+
+def test_conv_ops_takes_the_4x4_tile_only_when_asked_and_only_on_wide_layers(monkeypatch):
+    from video_frame_inpainting_amd import conv_ops
+    monkeypatch.setattr(conv_ops, 'WINO43_MIN_WORKGROUPS', 1)
+    x, w, b = _operands(16, 128, 128, 32, 32)          # (conv_ops leaves layers of fewer than 72 F(2x2, 3x3) workgroups to MIOpen)
+    xs, ws, bs = _operands(16, 64, 64, 32, 32)
+    with torch.no_grad():
+        y2, y2s = conv_ops.conv_bias_act(x, w, b, 1, 'relu'), conv_ops.conv_bias_act(xs, ws, bs, 1, 'relu')
+        prev = conv_ops.set_winograd_tile(4)
+        try:
+            assert prev == 2 and conv_ops.get_winograd_tile() == 4
+            y4, y4s = conv_ops.conv_bias_act(x, w, b, 1, 'relu'), conv_ops.conv_bias_act(xs, ws, bs, 1, 'relu')
+            y4p = conv_ops.conv_bias_act((x[:, :64].contiguous(), x[:, 64:].contiguous()), w, b, 1, 'relu')
+        finally:
+            conv_ops.set_winograd_tile(prev)
+    assert torch.equal(y4s, y2s)                                  # C = K = 64: stays on F(2x2, 3x3)
+    assert not torch.equal(y4, y2) and torch.equal(y4, _run([x], w, b, 'relu')) and torch.equal(y4p, y4)
+    assert float((y4 - y2).abs().max()) <= 1e-4 * float(y2.abs().max())
+    with pytest.raises(ValueError):
+        conv_ops.set_winograd_tile(3)
+
+
+def test_full_width_forward_with_the_4x4_tile_matches_cpu_oracle(monkeypatch):
+    """The whole bi-TAI forward (TAI_gray, full width, 128x128, K = F = T = 5) with F(4x4, 3x3) on every layer it takes, against the CPU
+    oracle with the bound of the default path's own test (tests/test_gpu_model.py: 1e-4 of each output's magnitude; PSNR within 0.01 dB,
+    SSIM within 1e-4), and next to the default forward of the same weights."""
+    import numpy as np
+    import video_frame_inpainting_amd as vfi
+    from video_frame_inpainting_amd import conv_ops, metrics, synthetic
+    from oracle import tai_oracle
+    monkeypatch.setattr(conv_ops, 'WINO43_MIN_WORKGROUPS', 1)     # two clips: few workgroups per layer
+    m = synthetic.seeded_init(vfi.create_model('TAI_gray'), 0)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    clips = synthetic.make_clips(2, 15, 1, 128, 128, synthetic.SEEDS['cfg2'])
+    P, GT, Fo = (torch.from_numpy(x) for x in synthetic.split_clip(clips, 5, 5, 5))
+    with torch.no_grad():
+        ref = tai_oracle.tai_forward(sd, 1, 5, 51, 5, P, Fo)
+        m.to('cuda:0').eval()
+        o2 = m(5, P.cuda(), Fo.cuda())
+        prev = conv_ops.set_winograd_tile(4)
+        try:
+            o4 = m(5, P.cuda(), Fo.cuda())
+        finally:
+            conv_ops.set_winograd_tile(prev)
+    for k in ('pred', 'pred_forward', 'pred_backward', 'interp_net_outputs_1', 'interp_net_outputs_2'):
+        scale = float(ref[k].abs().max())
+        e4, e2 = float((o4[k].cpu() - ref[k]).abs().max()), float((o2[k].cpu() - ref[k]).abs().max())
+        print('%s: max |gpu - oracle| / max |oracle|: tile 4 %.2e, tile 2 %.2e' % (k, e4 / scale, e2 / scale))
+        assert e4 <= 1e-4 * scale, (k, e4, e2, scale)
+        assert not torch.equal(o4[k], o2[k])                      # the F(4x4, 3x3) kernel did run
+    p4, s4, _ = metrics.compute_errors(o4['pred'].cpu().numpy(), GT.numpy())
+    pr, sr, _ = metrics.compute_errors(ref['pred'].numpy(), GT.numpy())
+    assert np.abs(np.asarray(p4) - np.asarray(pr)).max() <= 0.01 and np.abs(np.asarray(s4) - np.asarray(sr)).max() <= 1e-4

@@ -66,6 +66,34 @@ def get_winograd_arithmetic():
     return [k for k, v in WINOGRAD_ARITHMETICS.items() if v == mode][0]
 
 
+_WINO_TILE = [2]
+WINO43_MIN_CHANNELS = 128        # F(4x4, 3x3) only where both C and K are at least this (profiles/r04_wino_f43_study.txt: parity-neutral there)
+WINO43_MIN_WORKGROUPS = 400      # ... and where its 64-channel x 32-tile workgroups fill the chip at least ~1.6 times over
+
+
+def set_winograd_tile(m):
+    """Output tile of the Winograd 3x3 convolutions of the inference path: 2 (default: F(2x2, 3x3), csrc/wino_conv.hip.inc, every layer) or
+    4 (opt-in: F(4x4, 3x3), csrc/wino43_conv.hip.inc, on the plain and channel-part layers with C >= 128 and K >= 128 and enough
+    workgroups -- 1.78x fewer MFMAs at ~7x the fp32 rounding error per layer; restricted to those layers the forward's end-to-end error
+    is unchanged, profiles/r04_wino_f43_study.txt).  Layers with a fused second output (max pool, unpool + add), the displaced-read
+    5x5 / 7x7 layers and everything under autograd stay on F(2x2, 3x3).  A hipGraph captured before the switch keeps replaying what it
+    captured.  Returns the previous value."""
+    if m not in (2, 4):
+        raise ValueError(m)
+    prev, _WINO_TILE[0] = _WINO_TILE[0], m
+    return prev
+
+
+def get_winograd_tile():
+    return _WINO_TILE[0]
+
+
+def _wino43_ok(N, Ci, Co, H, W, nparts=1):
+    return (_WINO_TILE[0] == 4 and Ci >= WINO43_MIN_CHANNELS and Co >= WINO43_MIN_CHANNELS and H % 4 == 0 and W % 4 == 0
+            and Ci % nparts == 0 and (Ci // nparts) % 4 == 0 and N * max(Ci, Co) * H * W < 2 ** 29
+            and ((N * (H // 4) * (W // 4) + 31) // 32) * ((Co + 63) // 64) >= WINO43_MIN_WORKGROUPS)
+
+
 def _cached(weight, tag, make):
     """Derived form of a weight, kept on the tensor object and rebuilt when the weight's version counter or storage
     moves, or after ``invalidate_derived``."""
@@ -93,6 +121,20 @@ def _wino_weights(weight, transposed):
                           'tai_conv3x3_wino_transform_weights')
         return U
     return _cached(weight, ('wino', transposed), make)
+
+
+def _wino43_weights(weight, transposed):
+    def make():
+        w = _as_conv_weight(weight.detach(), transposed).contiguous()
+        K, C = w.shape[0], w.shape[1]
+        L = _native.lib()
+        U = torch.empty(L.tai_conv3x3_wino43_weight_floats(K, C), dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _native.check(L.tai_conv3x3_wino43_transform_weights(w.data_ptr(), U.data_ptr(), K, C,
+                                                                 torch.cuda.current_stream(w.device).cuda_stream),
+                          'tai_conv3x3_wino43_transform_weights')
+        return U
+    return _cached(weight, ('wino43', transposed), make)
 
 
 def _block3x3_weight(weight):
@@ -759,10 +801,16 @@ def _conv_bias_act(x, weight, bias, padding, act, transposed, out):
                 return _WinoConv3x3Parts.apply(weight, bias, act, transposed, *parts)     # training: the parts are read where they lie
             return _conv_bias_act(torch.cat(parts, dim=1), weight, bias, padding, act, transposed, out)
         L = _native.lib()
-        U = _wino_weights(weight, transposed)
         y = out if _usable_out(out, (N, Co, H, W), x0) else torch.empty((N, Co, H, W), dtype=x0.dtype, device=x0.device)
         ptrs = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
         with torch.cuda.device(x0.device):
+            if _wino43_ok(N, Ci, Co, H, W, len(parts)):      # opt-in: F(4x4, 3x3) (set_winograd_tile)
+                U = _wino43_weights(weight, transposed)
+                _native.check(L.tai_conv3x3_wino43_forward_parts(ptrs, len(parts), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci,
+                                                                 Co, H, W, _ACT[act], torch.cuda.current_stream(x0.device).cuda_stream),
+                              'tai_conv3x3_wino43_forward_parts')
+                return y
+            U = _wino_weights(weight, transposed)
             _native.check(L.tai_conv3x3_wino_forward_parts(ptrs, len(parts), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci,
                                                            Co, H, W, _ACT[act], torch.cuda.current_stream(x0.device).cuda_stream),
                           'tai_conv3x3_wino_forward_parts')
@@ -815,9 +863,14 @@ def _conv_bias_act(x, weight, bias, padding, act, transposed, out):
     if _wino_ok(N, Ci, Co, H, W, kh, kw, padding, min_ci=2):
         # Winograd F(2x2,3x3) on the fp32 MFMA pipe (csrc/wino_conv.hip.inc)
         x = x.contiguous()
-        U = _wino_weights(weight, transposed)
         y = out if _usable_out(out, (N, Co, H, W), x) else torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device)
         with torch.cuda.device(x.device):
+            if _wino43_ok(N, Ci, Co, H, W):                  # opt-in: F(4x4, 3x3) (set_winograd_tile)
+                U = _wino43_weights(weight, transposed)
+                _native.check(L.tai_conv3x3_wino43_forward(x.data_ptr(), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci, Co,
+                                                           H, W, _ACT[act], stream), 'tai_conv3x3_wino43_forward')
+                return y
+            U = _wino_weights(weight, transposed)
             _native.check(L.tai_conv3x3_wino_forward(x.data_ptr(), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci, Co,
                                                      H, W, _ACT[act], stream), 'tai_conv3x3_wino_forward')
         return y

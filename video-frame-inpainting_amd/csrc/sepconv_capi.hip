@@ -678,17 +678,21 @@ int tai_conv3x3_wino43_transform_weights(const float* weight, float* U, int K, i
     return check_launch("wino43_transform_weights");
 }
 
-int tai_conv3x3_wino43_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W, int act,
-                               void* hip_stream) {
-    g_err[0] = 0;
-    if (!x || !U || !bias || !y || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0)
-        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: bad argument");
-    if (H % 4 != 0 || W % 4 != 0 || C % wino43::KC != 0 || act < 0 || act > 2)
-        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: needs H, W and C multiples of 4, act in {0, 1, 2}");
+static int wino43_forward_impl(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C, int K, int H,
+                               int W, int act, void* hip_stream) {
+    if (!xs || !xs[0] || !U || !bias || !y || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || nparts < 1 || nparts > 4)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: bad argument (1 to 4 input parts)");
+    if (H % 4 != 0 || W % 4 != 0 || C % nparts != 0 || (C / nparts) % wino43::KC != 0 || act < 0 || act > 2)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: needs H, W and the channels of a part multiples of 4, act in {0, 1, 2}");
     if ((long long)N * C * H * W >= (1LL << 29) || (long long)N * K * H * W >= (1LL << 29))
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: tensor too large (2^29 elements or more)");
+    const float* p[4] = {xs[0], xs[0], xs[0], xs[0]};
+    for (int i = 0; i < nparts; ++i) {
+        if (!xs[i]) return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: null input part");
+        p[i] = xs[i];
+    }
     const int Kpad = (K + wino43::TM - 1) / wino43::TM * wino43::TM;
-    const int kblocks = Kpad / wino43::TM, nchunks = C / wino43::KC;
+    const int kblocks = Kpad / wino43::TM, nchunks = C / wino43::KC, cpart = C / nparts;
     const long long tiles = (long long)N * (H / 4) * (W / 4);
     const long long tblocks = (tiles + wino43::TN - 1) / wino43::TN;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
@@ -696,12 +700,25 @@ int tai_conv3x3_wino43_forward(const float* x, const float* U, const float* bias
     {                                                                                                                           \
         auto kern = wino43::conv3x3<A>;                                                                                         \
         if (int rc = allow_lds(kern, wino43::LDS_BYTES)) return rc;                                                             \
-        hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(256), wino43::LDS_BYTES, s, x, U, bias, y, N, C, K, H, W, \
-                           Kpad, nchunks, kblocks);                                                                             \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(256), wino43::LDS_BYTES, s, p[0], p[1], p[2], p[3], cpart, \
+                           U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks);                                                  \
     }
     if (act == 0) TAI_W43_LAUNCH(0) else if (act == 1) TAI_W43_LAUNCH(1) else TAI_W43_LAUNCH(2)
 #undef TAI_W43_LAUNCH
     return check_launch("conv3x3_wino43");
+}
+
+int tai_conv3x3_wino43_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W, int act,
+                               void* hip_stream) {
+    g_err[0] = 0;
+    const float* xs[1] = {x};
+    return wino43_forward_impl(xs, 1, U, bias, y, N, C, K, H, W, act, hip_stream);
+}
+
+int tai_conv3x3_wino43_forward_parts(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C, int K,
+                                     int H, int W, int act, void* hip_stream) {
+    g_err[0] = 0;
+    return wino43_forward_impl(xs, nparts, U, bias, y, N, C, K, H, W, act, hip_stream);
 }
 
 // Split of the weight-gradient kernel's reduction (the tiles) over workgroups: about one workgroup per CU in total.
