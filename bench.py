@@ -419,49 +419,60 @@ def secondary_configs(device, parity=True):
             log('%s parity on one clip: %s' % (name, res[name]['parity_one_clip']['max_abs_over_max_ref']))
         del g, m, P, Fo
         torch.cuda.empty_cache()
-    # configs[1] once more with the Winograd GEMMs in the OPT-IN split-bf16 arithmetic (three bf16 terms per fp32 operand, six bf16
-    # products per product, fp32 accumulation: csrc/wino_split.hip.inc).  Not the headline: that stays on the fp32 MFMA (`dtype f32`).
+    # configs[1] once more in the two OPT-IN arithmetics of the 3x3 convolutions -- neither is the headline, which stays on F(2x2, 3x3) on
+    # the fp32 MFMA (`dtype f32`): (1) split bf16 (three bf16 terms per fp32 operand, six bf16 products per product, fp32 accumulation:
+    # csrc/wino_split.hip.inc); (2) F(4x4, 3x3) on the fp32 MFMA for the layers with C >= 128 and K >= 128 (csrc/wino43_conv.hip.inc)
     from video_frame_inpainting_amd import conv_ops
-    prev = conv_ops.set_winograd_arithmetic('bf16x3')
-    try:
-        B, C, H, W, K, T, F = 32, 1, 128, 128, 5, 5, 5
-        m = synthetic.seeded_init(vfi.create_model('TAI_gray'), WEIGHT_SEED).to(device).eval()
-        clips = synthetic.make_clips(B, K + T + F, C, H, W, synthetic.SEEDS['cfg2'])
-        P, _, Fo = (torch.from_numpy(x).to(device) for x in synthetic.split_clip(clips, K, T, F))
-        g = GraphedForward(m, T, P, Fo, warmup=1)
-        for _ in range(2):
-            g()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 5
-        for _ in range(n):
-            g()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
-        name = 'configs[1], split-bf16 Winograd arithmetic (opt-in)'
-        res[name] = {'model': 'TAI_gray', 'clips': B, 'frame': [C, H, W], 'K_T_F': [K, T, F], 'ms_per_step': round(dt * 1e3, 2),
-                     'frames_per_s': round(B * T / dt, 1),
-                     'arithmetic': 'fp32 operands as hi + mid + lo bf16 terms, 6 of the 9 bf16 products, fp32 accumulate (v_mfma_f32_32x32x16_bf16); '
-                                   'layers the split kernel does not take (5x5 / 7x7 displaced reads) stay on the fp32 MFMA'}
-        log('%s: %.1f ms per step, %.1f frames/s' % (name, dt * 1e3, B * T / dt))
-        if parity:
-            from oracle import tai_oracle
-            sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
-            Pc, GTc, Fc = (torch.from_numpy(x) for x in synthetic.split_clip(clips[:1], K, T, F))
-            with torch.no_grad():
-                ref = tai_oracle.tai_forward(sd, C, 5, 51, T, Pc, Fc)
-                out = m(T, Pc.to(device), Fc.to(device))
-            pg, sg, _ = metrics.compute_errors(out['pred'].cpu().numpy(), GTc.numpy())
-            pc, sc_, _ = metrics.compute_errors(ref['pred'].numpy(), GTc.numpy())
-            res[name]['parity_one_clip'] = {
-                'max_abs_over_max_ref': {k: float('%.3g' % float((out[k].cpu() - ref[k]).abs().max() / ref[k].abs().max()))
-                                         for k in ('pred', 'pred_forward', 'pred_backward')},
-                'max_abs_psnr_delta_db': float(np.max(np.abs(pg - pc))), 'max_abs_ssim_delta': float(np.max(np.abs(sg - sc_)))}
-            log('%s parity on one clip: %s' % (name, res[name]['parity_one_clip']['max_abs_over_max_ref']))
-        del g, m, P, Fo
-        torch.cuda.empty_cache()
-    finally:
-        conv_ops.set_winograd_arithmetic(prev)
+
+    def optin_leg(name, note, enter, leave):
+        prev = enter()
+        try:
+            B, C, H, W, K, T, F = 32, 1, 128, 128, 5, 5, 5
+            m = synthetic.seeded_init(vfi.create_model('TAI_gray'), WEIGHT_SEED).to(device).eval()
+            clips = synthetic.make_clips(B, K + T + F, C, H, W, synthetic.SEEDS['cfg2'])
+            P, _, Fo = (torch.from_numpy(x).to(device) for x in synthetic.split_clip(clips, K, T, F))
+            g = GraphedForward(m, T, P, Fo, warmup=1)
+            for _ in range(2):
+                g()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 5
+            for _ in range(n):
+                g()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            res[name] = {'model': 'TAI_gray', 'clips': B, 'frame': [C, H, W], 'K_T_F': [K, T, F], 'ms_per_step': round(dt * 1e3, 2),
+                         'frames_per_s': round(B * T / dt, 1), 'arithmetic': note}
+            log('%s: %.1f ms per step, %.1f frames/s' % (name, dt * 1e3, B * T / dt))
+            if parity:
+                from oracle import tai_oracle
+                sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+                Pc, GTc, Fc = (torch.from_numpy(x) for x in synthetic.split_clip(clips[:1], K, T, F))
+                with torch.no_grad():
+                    ref = tai_oracle.tai_forward(sd, C, 5, 51, T, Pc, Fc)
+                    # (eight clips on the GPU, the first one compared: a one-clip batch has too few workgroups per layer for F(4x4, 3x3))
+                    out = m(T, P[:8], Fo[:8])
+                    out = {k: v[:1] for k, v in out.items()}
+                pg, sg, _ = metrics.compute_errors(out['pred'].cpu().numpy(), GTc.numpy())
+                pc, sc_, _ = metrics.compute_errors(ref['pred'].numpy(), GTc.numpy())
+                res[name]['parity_one_clip'] = {
+                    'max_abs_over_max_ref': {k: float('%.3g' % float((out[k].cpu() - ref[k]).abs().max() / ref[k].abs().max()))
+                                             for k in ('pred', 'pred_forward', 'pred_backward')},
+                    'max_abs_psnr_delta_db': float(np.max(np.abs(pg - pc))), 'max_abs_ssim_delta': float(np.max(np.abs(sg - sc_)))}
+                log('%s parity on one clip: %s' % (name, res[name]['parity_one_clip']['max_abs_over_max_ref']))
+            del g, m, P, Fo
+            torch.cuda.empty_cache()
+        finally:
+            leave(prev)
+
+    optin_leg('configs[1], split-bf16 Winograd arithmetic (opt-in)',
+              'fp32 operands as hi + mid + lo bf16 terms, 6 of the 9 bf16 products, fp32 accumulate (v_mfma_f32_32x32x16_bf16); '
+              'layers the split kernel does not take (5x5 / 7x7 displaced reads) stay on the fp32 MFMA',
+              lambda: conv_ops.set_winograd_arithmetic('bf16x3'), conv_ops.set_winograd_arithmetic)
+    optin_leg('configs[1], Winograd F(4x4,3x3) on the wide layers (opt-in)',
+              'fp32 on the fp32 MFMA (v_mfma_f32_16x16x4_f32), 36 multiplies per 4x4 output tile instead of 16 per 2x2, on the plain and '
+              'channel-part layers with C >= 128 and K >= 128 and >= 400 workgroups; every other layer as in the headline',
+              lambda: conv_ops.set_winograd_tile(4), conv_ops.set_winograd_tile)
     # the three-channel sepconv forward at configs[3]'s launch shape [T*B = 80, 3, 256, 256] would be 2.3 GB of taps; the
     # per-time-step shape [16,3,256,256] is the one SURVEY.md 8(a) tabulates
     ks, B, C, H, W = 51, 16, 3, 256, 256
