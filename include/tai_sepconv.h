@@ -230,6 +230,10 @@ long long tai_conv3x3_wino43_weight_floats(int K, int C);
 int tai_conv3x3_wino43_transform_weights(const float* weight, float* U, int K, int C, void* hip_stream);
 int tai_conv3x3_wino43_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W, int act,
                                void* hip_stream);
+/* Waves per workgroup of that kernel, process-wide: 8 (default: two per SIMD, 16 channels x 16 tiles each) or 4 (one per SIMD, 32 x 16
+ * each; A/B); the same bits.
+ * Returns the previous value, -1 on a bad one. */
+int tai_conv3x3_wino43_set_waves(int waves);
 /* ... with the input given as 1 to 4 equal channel parts (contiguous [N, C / nparts, H, W] tensors; C / nparts a multiple of 4): the
  * operands of a torch.cat along the channels that is never materialised (tai_conv3x3_wino_forward_parts' counterpart). */
 int tai_conv3x3_wino43_forward_parts(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C, int K,

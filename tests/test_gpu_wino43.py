@@ -99,11 +99,25 @@ def test_wino43_rejects_what_it_cannot_run():
     assert L.tai_conv3x3_wino43_forward(None, U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 8, 64, 8, 8, 0, s) != 0
 
 
-def test_wino43_is_bit_reproducible():
+def test_wino43_is_bit_reproducible_and_both_workgroup_forms_give_the_same_bits():
+    from video_frame_inpainting_amd import _native
+    L = _native.lib()
     x, w, b = _operands(8, 256, 256, 32, 32)
     first = _run([x], w, b, 'relu').clone()
     for _ in range(20):
         assert torch.equal(_run([x], w, b, 'relu'), first)
+    assert L.tai_conv3x3_wino43_set_waves(3) == -1
+    prev = L.tai_conv3x3_wino43_set_waves(4)            # one wave per SIMD (32 channels x 16 tiles per wave) against the default's two
+    try:
+        assert prev == 8
+        for shape in ((8, 256, 256, 32, 32), (2, 8, 70, 12, 12), (3, 128, 128, 8, 20)):
+            x, w, b = _operands(*shape)
+            four = _run([x], w, b, 'tanh').clone()
+            L.tai_conv3x3_wino43_set_waves(8)
+            assert torch.equal(_run([x], w, b, 'tanh'), four)
+            L.tai_conv3x3_wino43_set_waves(4)
+    finally:
+        L.tai_conv3x3_wino43_set_waves(prev)
 
 
 def test_conv_ops_takes_the_4x4_tile_only_when_asked_and_only_on_wide_layers(monkeypatch):
