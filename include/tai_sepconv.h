@@ -230,6 +230,12 @@ long long tai_conv3x3_wino43_weight_floats(int K, int C);
 int tai_conv3x3_wino43_transform_weights(const float* weight, float* U, int K, int C, void* hip_stream);
 int tai_conv3x3_wino43_forward(const float* x, const float* U, const float* bias, float* y, int N, int C, int K, int H, int W, int act,
                                void* hip_stream);
+/* ... the general form: 1 to 4 input parts and the second outputs of tai_conv3x3_wino_forward_ex that a 4 x 4 tile can hold --
+ *   ypool [N,K,H/2,W/2]  the 2x2 max pool of the activated output (act 0 or 1), or NULL;
+ *   addx  [N,K,H/2,W/2]  y2 = y + fixed_unpooling(addx) (act 0, no ypool); with y2 NULL the sum is written to y and the plain output
+ *                        is not produced. */
+int tai_conv3x3_wino43_forward_ex(const float* const* xs, int nparts, const float* U, const float* bias, float* y, float* ypool,
+                                  const float* addx, float* y2, int N, int C, int K, int H, int W, int act, void* hip_stream);
 /* Waves per workgroup of that kernel, process-wide: 8 (default: two per SIMD, 16 channels x 16 tiles each) or 4 (one per SIMD, 32 x 16
  * each; A/B); the same bits.
  * Returns the previous value, -1 on a bad one. */

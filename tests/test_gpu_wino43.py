@@ -85,6 +85,65 @@ def test_wino43_reads_channel_parts_without_a_cat(nparts):
     assert torch.equal(_run(parts, w, b, 'relu'), _run([torch.cat(parts, 1)], w, b, 'relu'))
 
 
+@pytest.mark.parametrize('shape,nparts', [((3, 128, 128, 16, 24), 1), ((2, 64, 70, 8, 8), 2), ((4, 256, 128, 32, 32), 2)])
+def test_wino43_pooled_and_unpool_add_outputs(shape, nparts):
+    """The second outputs of the general entry point against the plain launch: ypool = max_pool2d(relu(y), 2) exactly; y2 = y +
+    fixed_unpooling(addx) exactly (the plain output untouched); the sum alone in y when y2 is NULL."""
+    from video_frame_inpainting_amd import _native
+    L = _native.lib()
+    N, C, K, H, W = shape
+    x, w, b = _operands(*shape)
+    parts = [c.contiguous() for c in x.chunk(nparts, 1)]
+    s = torch.cuda.current_stream().cuda_stream
+    U = torch.empty(L.tai_conv3x3_wino43_weight_floats(K, C), device='cuda')
+    _native.check(L.tai_conv3x3_wino43_transform_weights(w.data_ptr(), U.data_ptr(), K, C, s), 'transform')
+    ptrs = (ctypes.c_void_p * nparts)(*[p.data_ptr() for p in parts])
+    for act in (None, 'relu'):
+        plain = _run(parts, w, b, act)
+        y = torch.full((N, K, H, W), float('nan'), device='cuda')
+        yp = torch.full((N, K, H // 2, W // 2), float('nan'), device='cuda')
+        _native.check(L.tai_conv3x3_wino43_forward_ex(ptrs, nparts, U.data_ptr(), b.data_ptr(), y.data_ptr(), yp.data_ptr(), None, None, N, C, K, H, W,
+                                                      _ACT[act], s), 'ex pool')
+        assert torch.equal(y, plain) and torch.equal(yp, F.max_pool2d(plain, 2))
+    plain = _run(parts, w, b, None)
+    addx = torch.randn(N, K, H // 2, W // 2, generator=torch.Generator().manual_seed(5)).cuda()
+    want = plain.clone()
+    want[:, :, 0::2, 0::2] += addx
+    y = torch.full((N, K, H, W), float('nan'), device='cuda')
+    y2 = torch.full((N, K, H, W), float('nan'), device='cuda')
+    _native.check(L.tai_conv3x3_wino43_forward_ex(ptrs, nparts, U.data_ptr(), b.data_ptr(), y.data_ptr(), None, addx.data_ptr(), y2.data_ptr(), N, C, K, H,
+                                                  W, 0, s), 'ex add')
+    assert torch.equal(y, plain) and torch.equal(y2, want)
+    y.fill_(float('nan'))
+    _native.check(L.tai_conv3x3_wino43_forward_ex(ptrs, nparts, U.data_ptr(), b.data_ptr(), y.data_ptr(), None, addx.data_ptr(), None, N, C, K, H, W, 0, s),
+                  'ex sum')
+    assert torch.equal(y, want)
+    # refusals: y2 without addx, addx with an activation
+    assert L.tai_conv3x3_wino43_forward_ex(ptrs, nparts, U.data_ptr(), b.data_ptr(), y.data_ptr(), None, None, y2.data_ptr(), N, C, K, H, W, 0, s) != 0
+    assert L.tai_conv3x3_wino43_forward_ex(ptrs, nparts, U.data_ptr(), b.data_ptr(), y.data_ptr(), None, addx.data_ptr(), None, N, C, K, H, W, 1, s) != 0
+
+
+def test_conv_ops_second_output_layers_take_the_4x4_tile(monkeypatch):
+    from video_frame_inpainting_amd import conv_ops
+    monkeypatch.setattr(conv_ops, 'WINO43_MIN_WORKGROUPS', 1)
+    x, w, b = _operands(16, 128, 128, 32, 32)
+    addx = torch.randn(16, 128, 16, 16, generator=torch.Generator().manual_seed(9)).cuda()
+    with torch.no_grad():
+        y2, yp2 = conv_ops.conv_bias_act_maxpool(x, w, b, 1, 'relu')
+        p2, s2 = conv_ops.conv_bias_unpool_add(x, w, b, 1, addx)
+        prev = conv_ops.set_winograd_tile(4)
+        try:
+            y4, yp4 = conv_ops.conv_bias_act_maxpool(x, w, b, 1, 'relu')
+            p4, s4 = conv_ops.conv_bias_unpool_add((x[:, :64].contiguous(), x[:, 64:].contiguous()), w, b, 1, addx)
+            _, s4only = conv_ops.conv_bias_unpool_add(x, w, b, 1, addx, keep_plain=False)
+        finally:
+            conv_ops.set_winograd_tile(prev)
+    assert torch.equal(y4, _run([x], w, b, 'relu')) and torch.equal(yp4, F.max_pool2d(y4, 2)) and not torch.equal(y4, y2)
+    assert torch.equal(p4, _run([x], w, b, None)) and torch.equal(s4only, s4) and not torch.equal(p4, p2)
+    for a, c in ((y4, y2), (yp4, yp2), (p4, p2), (s4, s2)):
+        assert float((a - c).abs().max()) <= 1e-4 * float(c.abs().max())
+
+
 def test_wino43_rejects_what_it_cannot_run():
     from video_frame_inpainting_amd import _native
     L = _native.lib()

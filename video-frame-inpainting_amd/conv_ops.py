@@ -295,10 +295,17 @@ def conv_bias_unpool_add(x, weight, bias, padding, addx, keep_plain=True):
     L = _native.lib()
     parts = [q.contiguous() for q in parts]
     addx = addx.contiguous()
-    U = _wino_weights(weight, False)
     y = torch.empty((N, Co, H, W), dtype=torch.float32, device=x0.device)
     y2 = torch.empty_like(y) if keep_plain else None
     ptrs = (ctypes.c_void_p * len(parts))(*[q.data_ptr() for q in parts])
+    if _wino43_ok(N, Ci, Co, H, W, len(parts)):              # opt-in: F(4x4, 3x3) (set_winograd_tile): a tile holds four unpooling cells
+        U = _wino43_weights(weight, False)
+        with torch.cuda.device(x0.device):
+            _native.check(L.tai_conv3x3_wino43_forward_ex(ptrs, len(parts), U.data_ptr(), bias.data_ptr(), y.data_ptr(), None, addx.data_ptr(),
+                                                          y2.data_ptr() if keep_plain else None, N, Ci, Co, H, W, 0,
+                                                          torch.cuda.current_stream(x0.device).cuda_stream), 'tai_conv3x3_wino43_forward_ex')
+        return (y, y2) if keep_plain else (None, y)
+    U = _wino_weights(weight, False)
     with torch.cuda.device(x0.device):
         _native.check(L.tai_conv3x3_wino_forward_ex(ptrs, len(parts), 0, U.data_ptr(), bias.data_ptr(), y.data_ptr(), None, 0, 0, 0, 0,
                                                    addx.data_ptr(), y2.data_ptr() if keep_plain else None, N, Ci, Co, H, W, H, W, 0, 0, 0,
@@ -752,6 +759,11 @@ def conv_bias_act_maxpool(x, weight, bias, padding, act):
                     _native.check(L.tai_conv_cin1_forward_maxpool(x.data_ptr(), weight.contiguous().data_ptr(), bias.data_ptr(),
                                                                   y.data_ptr(), yp.data_ptr(), N, Co, H, W, kh, _ACT[act], stream),
                                   'tai_conv_cin1_forward_maxpool')
+                elif kh == kw == 3 and padding == 1 and _wino43_ok(N, Ci, Co, H, W):      # opt-in: F(4x4, 3x3): a tile is four pooling windows
+                    U = _wino43_weights(weight, False)
+                    xs = (ctypes.c_void_p * 1)(x.data_ptr())
+                    _native.check(L.tai_conv3x3_wino43_forward_ex(xs, 1, U.data_ptr(), bias.data_ptr(), y.data_ptr(), yp.data_ptr(), None, None,
+                                                                  N, Ci, Co, H, W, _ACT[act], stream), 'tai_conv3x3_wino43_forward_ex')
                 else:
                     U = _wino_weights(weight, False)
                     _native.check(L.tai_conv3x3_wino_forward_maxpool(x.data_ptr(), U.data_ptr(), bias.data_ptr(), y.data_ptr(),

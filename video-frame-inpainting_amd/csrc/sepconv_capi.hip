@@ -685,13 +685,15 @@ int tai_conv3x3_wino43_set_waves(int waves) {
 }
 
 static int wino43_forward_impl(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C, int K, int H,
-                               int W, int act, void* hip_stream) {
+                               int W, int act, void* hip_stream, float* ypool = nullptr, const float* addx = nullptr, float* y2 = nullptr) {
     if (!xs || !xs[0] || !U || !bias || !y || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || nparts < 1 || nparts > 4)
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: bad argument (1 to 4 input parts)");
     if (H % 4 != 0 || W % 4 != 0 || C % nparts != 0 || (C / nparts) % wino43::KC != 0 || act < 0 || act > 2)
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: needs H, W and the channels of a part multiples of 4, act in {0, 1, 2}");
     if ((long long)N * C * H * W >= (1LL << 29) || (long long)N * K * H * W >= (1LL << 29))
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: tensor too large (2^29 elements or more)");
+    if ((y2 && !addx) || (addx && (act != 0 || ypool)) || (ypool && act == 2))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43_ex: y2 needs addx; addx needs act 0 and no pooled output; no pooled output with tanh");
     const float* p[4] = {xs[0], xs[0], xs[0], xs[0]};
     for (int i = 0; i < nparts; ++i) {
         if (!xs[i]) return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: null input part");
@@ -702,17 +704,21 @@ static int wino43_forward_impl(const float* const* xs, int nparts, const float* 
     const long long tiles = (long long)N * (H / 4) * (W / 4);
     const long long tblocks = (tiles + wino43::TN - 1) / wino43::TN;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-#define TAI_W43_LAUNCH(A, W8)                                                                                                   \
+#define TAI_W43_LAUNCH(A, W8, E)                                                                                                \
     {                                                                                                                           \
-        auto kern = wino43::conv3x3<A, W8>;                                                                                     \
+        auto kern = wino43::conv3x3<A, W8, E>;                                                                                  \
         if (int rc = allow_lds(kern, wino43::LDS_BYTES)) return rc;                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(W8 ? 512 : 256), wino43::LDS_BYTES, s, p[0], p[1], p[2], p[3], \
-                           cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks);                                           \
+                           cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, ypool, addx, y2);                          \
     }
-    if (g_wino43_waves.load(std::memory_order_relaxed) == 8) {
-        if (act == 0) TAI_W43_LAUNCH(0, true) else if (act == 1) TAI_W43_LAUNCH(1, true) else TAI_W43_LAUNCH(2, true)
+    if (ypool) {                                   // second outputs: the eight-wave form only
+        if (act == 0) TAI_W43_LAUNCH(0, true, 1) else TAI_W43_LAUNCH(1, true, 1)
+    } else if (addx) {
+        if (y2) TAI_W43_LAUNCH(0, true, 2) else TAI_W43_LAUNCH(0, true, 3)
+    } else if (g_wino43_waves.load(std::memory_order_relaxed) == 8) {
+        if (act == 0) TAI_W43_LAUNCH(0, true, 0) else if (act == 1) TAI_W43_LAUNCH(1, true, 0) else TAI_W43_LAUNCH(2, true, 0)
     } else {
-        if (act == 0) TAI_W43_LAUNCH(0, false) else if (act == 1) TAI_W43_LAUNCH(1, false) else TAI_W43_LAUNCH(2, false)
+        if (act == 0) TAI_W43_LAUNCH(0, false, 0) else if (act == 1) TAI_W43_LAUNCH(1, false, 0) else TAI_W43_LAUNCH(2, false, 0)
     }
 #undef TAI_W43_LAUNCH
     return check_launch("conv3x3_wino43");
@@ -729,6 +735,12 @@ int tai_conv3x3_wino43_forward_parts(const float* const* xs, int nparts, const f
                                      int H, int W, int act, void* hip_stream) {
     g_err[0] = 0;
     return wino43_forward_impl(xs, nparts, U, bias, y, N, C, K, H, W, act, hip_stream);
+}
+
+int tai_conv3x3_wino43_forward_ex(const float* const* xs, int nparts, const float* U, const float* bias, float* y, float* ypool,
+                                  const float* addx, float* y2, int N, int C, int K, int H, int W, int act, void* hip_stream) {
+    g_err[0] = 0;
+    return wino43_forward_impl(xs, nparts, U, bias, y, N, C, K, H, W, act, hip_stream, ypool, addx, y2);
 }
 
 // Split of the weight-gradient kernel's reduction (the tiles) over workgroups: about one workgroup per CU in total.
