@@ -1,0 +1,32 @@
+"""Host side of the opt-in F(4x4, 3x3) path (conv_ops.set_winograd_tile): which layers take it.  No GPU, no compute calls."""
+import pytest
+
+
+def test_tile_switch_and_layer_selection():
+    from video_frame_inpainting_amd import conv_ops
+    assert conv_ops.get_winograd_tile() == 2
+    assert not conv_ops._wino43_ok(64, 256, 256, 32, 32)                 # default: every layer on F(2x2, 3x3)
+    with pytest.raises(ValueError):
+        conv_ops.set_winograd_tile(3)
+    prev = conv_ops.set_winograd_tile(4)
+    try:
+        assert prev == 2 and conv_ops.get_winograd_tile() == 4
+        assert conv_ops._wino43_ok(64, 256, 256, 32, 32)                 # 128 tile blocks x 4 channel blocks = 512 workgroups
+        assert conv_ops._wino43_ok(64, 512, 1024, 16, 16, nparts=2)      # the ConvLSTM's (input, h)
+        assert not conv_ops._wino43_ok(64, 64, 256, 32, 32)              # C < 128
+        assert not conv_ops._wino43_ok(64, 256, 64, 32, 32)              # K < 128
+        assert not conv_ops._wino43_ok(64, 256, 256, 30, 32)             # H % 4
+        assert not conv_ops._wino43_ok(64, 512, 256, 16, 16, nparts=2)   # 32 x 4 = 128 workgroups: too few
+        assert not conv_ops._wino43_ok(160, 256, 256, 16, 16)            # 80 x 4 = 320
+        assert not conv_ops._wino43_ok(64, 384, 256, 32, 32, nparts=4) or (384 // 4) % 4 == 0
+        assert not conv_ops._wino43_ok(4096, 1024, 1024, 32, 32)         # 2^32 elements: beyond the kernel's 32-bit offsets
+    finally:
+        conv_ops.set_winograd_tile(prev)
+    assert conv_ops.get_winograd_tile() == 2
+
+
+def test_predict_option_exists():
+    from video_frame_inpainting_amd.options import TestOptions
+    opt = TestOptions().parse(['--name', 'x', '--model_key', 'TAI_gray', '--K', '5', '--T', '5', '--F', '5', '--qual_result_root', '/tmp/q', '--winograd_tile', '4',
+                              '--synthetic', '1'], allow_unknown=True, require_gpu=False)
+    assert opt.winograd_tile == 4
