@@ -233,31 +233,39 @@ def sepconv_in_model_roofline(device, B, reps=10):
 # (N, C, K, H, W, calls per forward) of the 3x3 convolutions of configs[1] (TAI_gray, 32 clips: both directions batched to
 # 64, the five kernel-network evaluations batched to 160), profiles/r01_conv_path_times.txt; the 5x5 / 7x7 layers appear
 # in the form the kernel sees them (4 / 9 shifted copies stacked on the channels).
+# (N, C, K, H, W, launches per step[, True: a 5x5 / 7x7 layer cut into 3x3 blocks -- displaced reads, F(2x2, 3x3) whatever its width])
 CONV_LAYERS = ((64, 64, 64, 128, 128, 15), (64, 128, 64, 128, 128, 5), (64, 64, 128, 64, 64, 5), (64, 128, 128, 64, 64, 15),
-               (64, 256, 128, 64, 64, 13), (64, 128, 256, 32, 32, 5), (64, 256, 256, 32, 32, 25), (64, 512, 256, 32, 32, 5),
-               (64, 1152, 256, 32, 32, 8), (64, 512, 1024, 16, 16, 8), (64, 512, 256, 16, 16, 5), (160, 51, 51, 128, 128, 4),
-               (160, 64, 64, 64, 64, 9), (160, 64, 51, 64, 64, 4), (160, 256, 64, 64, 64, 1), (160, 512, 128, 32, 32, 1),
-               (160, 1024, 256, 16, 16, 1), (160, 256, 256, 16, 16, 3))
+               (64, 256, 128, 64, 64, 8, True), (64, 256, 128, 64, 64, 5), (64, 128, 256, 32, 32, 5), (64, 256, 256, 32, 32, 25),
+               (64, 512, 256, 32, 32, 5), (64, 1152, 256, 32, 32, 8, True), (64, 512, 1024, 16, 16, 8), (64, 512, 256, 16, 16, 5),
+               (160, 51, 51, 128, 128, 4), (160, 64, 64, 64, 64, 9), (160, 64, 51, 64, 64, 4), (160, 256, 64, 64, 64, 1),
+               (160, 512, 128, 32, 32, 1), (160, 1024, 256, 16, 16, 1), (160, 256, 256, 16, 16, 3))
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA
 
 
 def conv_roofline(device):
     L = _native.lib()
     stream = torch.cuda.current_stream(device).cuda_stream
-    mfma_flops = direct_flops = seconds = 0.0
+    from video_frame_inpainting_amd import conv_ops
+    mfma_flops = direct_flops = seconds = s43 = 0.0
+    n43 = 0
     per_graph = 8
     with torch.no_grad():
-        for (N, C, K, H, W, calls) in CONV_LAYERS:
+        for layer in CONV_LAYERS:
+            (N, C, K, H, W, calls), kxk = layer[:6], len(layer) > 6
             g = torch.Generator().manual_seed(N + C + K)
             x = torch.randn(N, C, H, W, generator=g).to(device)
             w = (torch.randn(K, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).to(device)
             b = torch.zeros(K, device=device)
             y = torch.empty(N, K, H, W, device=device)
-            U = torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), device=device)
-            _native.check(L.tai_conv3x3_wino_transform_weights(w.data_ptr(), U.data_ptr(), K, C, stream), 'transform_weights')
+            # the kernel conv_ops dispatches this layer to: F(4x4, 3x3) on the wide layers (C, K >= 128, enough workgroups), else F(2x2, 3x3)
+            f43 = conv_ops._wino43_ok(N, C, K, H, W) and not kxk
+            pre = 'tai_conv3x3_wino43' if f43 else 'tai_conv3x3_wino'
+            U = torch.empty(getattr(L, pre + '_weight_floats')(K, C), device=device)
+            _native.check(getattr(L, pre + '_transform_weights')(w.data_ptr(), U.data_ptr(), K, C, stream), 'transform_weights')
+            fwd = getattr(L, pre + '_forward')
             def launch():
-                _native.check(L.tai_conv3x3_wino_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), N, C, K, H, W, 1,
-                                                         torch.cuda.current_stream(device).cuda_stream), 'wino_forward')
+                _native.check(fwd(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), N, C, K, H, W, 1,
+                                  torch.cuda.current_stream(device).cuda_stream), 'wino_forward')
             launch(); launch()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
@@ -272,16 +280,26 @@ def conv_roofline(device):
             t = e0.elapsed_time(e1) * 1e-3 / (2 * per_graph)
             seconds += t * calls
             direct_flops += 18.0 * N * K * C * H * W * calls
-            mfma_flops += 8.0 * N * K * C * H * W * calls
+            # multiply-adds the MFMA pipe is handed: 16 per 2x2 output tile (F(2x2, 3x3)) or 36 per 4x4 tile (F(4x4, 3x3)), per (c, k)
+            mfma_flops += (4.5 if f43 else 8.0) * N * K * C * H * W * calls
+            n43 += calls if f43 else 0
+            s43 += t * calls if f43 else 0.0
             del x, w, y, U, graph
     achieved = mfma_flops / seconds / 1e12
     return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': 'wino::conv3x3 (F(2x2,3x3), fp32 MFMA)',
+            'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+            'kernel': 'wino::conv3x3 (F(2x2,3x3)) and wino43::conv3x3 (F(4x4,3x3), the wide layers), fp32 MFMA, as conv_ops dispatches them',
             'layers': len(CONV_LAYERS), 'launches_per_step': sum(l[5] for l in CONV_LAYERS), 'ms_per_step_in_kernel': round(seconds * 1e3, 2),
+            'launches_per_step_f43': n43, 'ms_per_step_in_kernel_f43': round(s43 * 1e3, 2),
             'direct_conv_tflops': round(direct_flops / seconds / 1e12, 1),
-            'note': 'achieved = Winograd-domain multiply-adds (direct-convolution flops / 2.25, unpadded K and C) per second'}
+            'f2x2_equivalent': {'achieved': round(direct_flops / 2.25 / seconds / 1e12, 1), 'frac': round(direct_flops / 2.25 / seconds / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                'what': "direct-convolution flops / 2.25 per second: the MFMA rate an all-F(2x2,3x3) kernel would need for this time "
+                                        "(rounds 1-3 reported this figure as `frac`: 0.65-0.67)"},
+            'note': 'achieved = the multiply-adds handed to the MFMA pipe per second: direct-convolution flops / 2.25 on the F(2x2,3x3) '
+                    'layers, / 4 on the F(4x4,3x3) layers (unpadded K and C); F(4x4,3x3) lowers this utilisation figure and the time'}
 
 
+PARITY_BATCH = 32            # the parity block's GPU forward has the timed batch's shape (its first 8 clips are compared)
 GPU_BOX_CPU_SHARE = 16      # the pool's rule for a one-GPU box: "size worker pools to the box's CPU share (16 for one GPU)"
 
 
@@ -333,7 +351,11 @@ def cpu_baseline_and_parity(model, device, timed=3, cpu_threads=None):
             med, ts, ref = _median_time(fwd, timed)
             per_b[B] = {'frames_per_s': round(B * T_ / med, 3), 'median_s': round(med, 3), 'times_s': [round(t, 3) for t in ts]}
             log('cpu baseline: B=%d  %s s  -> %.2f frames/s' % (B, per_b[B]['times_s'], per_b[B]['frames_per_s']))
-        out = model(T_, P.to(device), Fo.to(device))
+        # the GPU side runs a batch of the TIMED shape (32 clips: which layers take F(4x4, 3x3) depends on the batch), the parity clips first
+        fill = synthetic.make_clips(PARITY_BATCH - n_clips, K_ + T_ + F_, C_, H_, W_, synthetic.SEEDS['cfg2'])
+        Pf, _, Ff = (torch.from_numpy(x) for x in synthetic.split_clip(fill, K_, T_, F_))
+        out = model(T_, torch.cat([P, Pf]).to(device), torch.cat([Fo, Ff]).to(device))
+        out = {k: v[:n_clips] for k, v in out.items()}
     # the sepconv loops alone (the C restatement of .cu:19-47) at [8,1,128,128]
     ks = 51
     g = torch.Generator().manual_seed(7)
@@ -364,7 +386,7 @@ def cpu_baseline_and_parity(model, device, timed=3, cpu_threads=None):
     p_cpu, s_cpu, _ = metrics.compute_errors(pred_cpu, GT.numpy())
     mse = float(((pred_gpu - pred_cpu) ** 2).mean())
     u8_gpu, u8_cpu = metrics.to_uint8(pred_gpu), metrics.to_uint8(pred_cpu)
-    parity = {'clips': n_clips, 'weights': 'synthetic.seeded_init(seed %d): N(0, 1/fan_in) weights, N(0, 0.01) biases' % WEIGHT_SEED,
+    parity = {'clips': n_clips, 'gpu_batch': PARITY_BATCH, 'weights': 'synthetic.seeded_init(seed %d): N(0, 1/fan_in) weights, N(0, 0.01) biases' % WEIGHT_SEED,
               'max_abs_over_max_ref': {k: float('%.3g' % v) for k, v in rel.items()},
               'max_abs_ref_pred': float(np.abs(pred_cpu).max()),
               'max_abs_pred': float(np.abs(pred_gpu - pred_cpu).max()), 'rms_pred': float(np.sqrt(mse)),
@@ -408,7 +430,7 @@ def secondary_configs(device, parity=True):
             Pc, GTc, Fc = (torch.from_numpy(x) for x in synthetic.split_clip(clips[:1], K, T, F))
             with torch.no_grad():
                 ref = tai_oracle.tai_forward(sd, C, 5 if C == 1 else 4, 51, T, Pc, Fc)
-                out = m(T, Pc.to(device), Fc.to(device))
+                out = {k: v[:1] for k, v in m(T, P, Fo).items()}        # the timed batch, its first clip compared
             pg, sg, _ = metrics.compute_errors(out['pred'].cpu().numpy(), GTc.numpy())
             pc, sc_, _ = metrics.compute_errors(ref['pred'].numpy(), GTc.numpy())
             res[name]['parity_one_clip'] = {
@@ -419,9 +441,9 @@ def secondary_configs(device, parity=True):
             log('%s parity on one clip: %s' % (name, res[name]['parity_one_clip']['max_abs_over_max_ref']))
         del g, m, P, Fo
         torch.cuda.empty_cache()
-    # configs[1] once more in the two OPT-IN arithmetics of the 3x3 convolutions -- neither is the headline, which stays on F(2x2, 3x3) on
-    # the fp32 MFMA (`dtype f32`): (1) split bf16 (three bf16 terms per fp32 operand, six bf16 products per product, fp32 accumulation:
-    # csrc/wino_split.hip.inc); (2) F(4x4, 3x3) on the fp32 MFMA for the layers with C >= 128 and K >= 128 (csrc/wino43_conv.hip.inc)
+    # configs[1] twice more: (1) in the OPT-IN split-bf16 arithmetic of the F(2x2, 3x3) GEMMs (three bf16 terms per fp32 operand, six bf16
+    # products per product, fp32 accumulation: csrc/wino_split.hip.inc) -- not the headline, which is fp32 on the fp32 MFMA throughout
+    # (`dtype f32`); (2) with F(2x2, 3x3) on every layer, the arithmetic of rounds 1-3, next to the headline's F(4x4, 3x3) on the wide layers
     from video_frame_inpainting_amd import conv_ops
 
     def optin_leg(name, note, enter, leave):
@@ -467,12 +489,11 @@ def secondary_configs(device, parity=True):
 
     optin_leg('configs[1], split-bf16 Winograd arithmetic (opt-in)',
               'fp32 operands as hi + mid + lo bf16 terms, 6 of the 9 bf16 products, fp32 accumulate (v_mfma_f32_32x32x16_bf16); '
-              'layers the split kernel does not take (5x5 / 7x7 displaced reads) stay on the fp32 MFMA',
+              'layers the split kernel does not take (5x5 / 7x7 displaced reads; the wide layers, which run F(4x4,3x3)) stay on the fp32 MFMA',
               lambda: conv_ops.set_winograd_arithmetic('bf16x3'), conv_ops.set_winograd_arithmetic)
-    optin_leg('configs[1], Winograd F(4x4,3x3) on the wide layers (opt-in)',
-              'fp32 on the fp32 MFMA (v_mfma_f32_16x16x4_f32), 36 multiplies per 4x4 output tile instead of 16 per 2x2, on the plain and '
-              'channel-part layers with C >= 128 and K >= 128 and >= 400 workgroups; every other layer as in the headline',
-              lambda: conv_ops.set_winograd_tile(4), conv_ops.set_winograd_tile)
+    optin_leg('configs[1], Winograd F(2x2,3x3) on every layer (the arithmetic of rounds 1-3, for reference)',
+              'fp32 on the fp32 MFMA; the headline runs the layers with C >= 128 and K >= 128 and >= 400 workgroups as F(4x4,3x3) instead',
+              lambda: conv_ops.set_winograd_tile(2), conv_ops.set_winograd_tile)
     # the three-channel sepconv forward at configs[3]'s launch shape [T*B = 80, 3, 256, 256] would be 2.3 GB of taps; the
     # per-time-step shape [16,3,256,256] is the one SURVEY.md 8(a) tabulates
     ks, B, C, H, W = 51, 16, 3, 256, 256
@@ -827,7 +848,9 @@ def main():
                                'sepconv HIP kernels + %s' % (B, 'eager launches' if args.no_graph else 'hipGraph replay'),
                    'clips_per_gpu': B, 'global_clips': world * B, 'parallelism': 'clip-sharded x%d, no collective' % world,
                    'ranks': world, 'backend': ('rccl (torch.distributed "nccl")' if backend == 'nccl' else backend),
-                   'weights': 'seeded N(0, 1/fan_in) weights and N(0, 0.01) biases (synthetic.seeded_init, seed %d)' % WEIGHT_SEED},
+                   'weights': 'seeded N(0, 1/fan_in) weights and N(0, 0.01) biases (synthetic.seeded_init, seed %d)' % WEIGHT_SEED,
+                   'convolutions': 'fp32 on the fp32 MFMA: Winograd F(4x4,3x3) on the 3x3 layers with C >= 128 and K >= 128 (and >= 400 '
+                                   'workgroups), F(2x2,3x3) on the others and on the 5x5 / 7x7 layers (conv_ops.set_winograd_tile)'},
     }
     if args.rehearse_one_gpu:
         line['rehearsal'] = 'all %d ranks on one GPU, gloo control plane: NOT a measurement' % world

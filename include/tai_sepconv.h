@@ -222,8 +222,9 @@ int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_k,
                                 float* ypool, int pool_h, int pool_w, int pool_oy, int pool_ox, const float* addx, float* y2, int N,
                                 int C, int K, int H, int W, int in_h, int in_w, int in_oy, int in_ox, int act, void* hip_stream);
 /* The same convolution as Winograd F(4x4, 3x3) on the fp32 MFMA pipe (csrc/wino43_conv.hip.inc): 36 multiplies per 4 x 4 output tile
- * instead of 16 per 2 x 2 -- 1.78x fewer MFMAs, ~7x the fp32 rounding error per layer; opt-in, and meant for the layers with C >= 128
- * and K >= 128, where the bi-TAI forward's end-to-end error is unchanged (profiles/r04_wino_f43_study.txt).  Own transformed-weight
+ * instead of 16 per 2 x 2 -- 1.78x fewer MFMAs, ~7x the fp32 rounding error per layer; meant for the layers with C >= 128 and
+ * K >= 128, where the bi-TAI forward's end-to-end error is unchanged (profiles/r04_wino_f43_study.txt, r04_wino43_default_parity.txt):
+ * the Python side (conv_ops) sends exactly those layers here by default.  Own transformed-weight
  * layout (tai_conv3x3_wino43_weight_floats / _transform_weights); H, W and C multiples of 4; act as above.  Replaces the same
  * reference layers as tai_conv3x3_wino_forward (src/models/mcnet/mcnet.py:79-118,131-152,165-176,198-224). */
 long long tai_conv3x3_wino43_weight_floats(int K, int C);

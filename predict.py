@@ -46,7 +46,7 @@ def main(args=None):
     if getattr(opt, 'winograd_arithmetic', 'fp32') != 'fp32':
         from video_frame_inpainting_amd import conv_ops
         conv_ops.set_winograd_arithmetic(opt.winograd_arithmetic)
-    if getattr(opt, 'winograd_tile', 2) != 2:
+    if getattr(opt, 'winograd_tile', None) in (2, 4):
         from video_frame_inpainting_amd import conv_ops
         conv_ops.set_winograd_tile(opt.winograd_tile)
     H, W = opt.image_size[0] + opt.padding_size[0], opt.image_size[1] + opt.padding_size[1]

@@ -1,4 +1,4 @@
-"""Winograd F(4x4, 3x3) on the fp32 MFMA pipe (csrc/wino43_conv.hip.inc; opt-in, conv_ops.set_winograd_tile(4)) against an fp64
+"""Winograd F(4x4, 3x3) on the fp32 MFMA pipe (csrc/wino43_conv.hip.inc; the wide layers of the inference path, conv_ops.set_winograd_tile) against an fp64
 convolution of the same operands, against the F(2x2, 3x3) kernel, and -- the whole bi-TAI forward -- against the CPU oracle.
 Reference layers: nn.Conv2d(C, K, 3, padding=1) (+ReLU) of src/models/mcnet/mcnet.py:79-118,131-152,165-176,198-224 and
 src/models/tai/tai.py:248-286."""
@@ -129,15 +129,16 @@ def test_conv_ops_second_output_layers_take_the_4x4_tile(monkeypatch):
     x, w, b = _operands(16, 128, 128, 32, 32)
     addx = torch.randn(16, 128, 16, 16, generator=torch.Generator().manual_seed(9)).cuda()
     with torch.no_grad():
+        before = conv_ops.set_winograd_tile(2)
         y2, yp2 = conv_ops.conv_bias_act_maxpool(x, w, b, 1, 'relu')
         p2, s2 = conv_ops.conv_bias_unpool_add(x, w, b, 1, addx)
-        prev = conv_ops.set_winograd_tile(4)
+        conv_ops.set_winograd_tile(4)
         try:
             y4, yp4 = conv_ops.conv_bias_act_maxpool(x, w, b, 1, 'relu')
             p4, s4 = conv_ops.conv_bias_unpool_add((x[:, :64].contiguous(), x[:, 64:].contiguous()), w, b, 1, addx)
             _, s4only = conv_ops.conv_bias_unpool_add(x, w, b, 1, addx, keep_plain=False)
         finally:
-            conv_ops.set_winograd_tile(prev)
+            conv_ops.set_winograd_tile(before)
     assert torch.equal(y4, _run([x], w, b, 'relu')) and torch.equal(yp4, F.max_pool2d(y4, 2)) and not torch.equal(y4, y2)
     assert torch.equal(p4, _run([x], w, b, None)) and torch.equal(s4only, s4) and not torch.equal(p4, p2)
     for a, c in ((y4, y2), (yp4, yp2), (p4, p2), (s4, s2)):
@@ -185,14 +186,15 @@ def test_conv_ops_takes_the_4x4_tile_only_when_asked_and_only_on_wide_layers(mon
     x, w, b = _operands(16, 128, 128, 32, 32)          # (conv_ops leaves layers of fewer than 72 F(2x2, 3x3) workgroups to MIOpen)
     xs, ws, bs = _operands(16, 64, 64, 32, 32)
     with torch.no_grad():
+        before = conv_ops.set_winograd_tile(2)
         y2, y2s = conv_ops.conv_bias_act(x, w, b, 1, 'relu'), conv_ops.conv_bias_act(xs, ws, bs, 1, 'relu')
         prev = conv_ops.set_winograd_tile(4)
         try:
-            assert prev == 2 and conv_ops.get_winograd_tile() == 4
+            assert before == 4 and prev == 2 and conv_ops.get_winograd_tile() == 4
             y4, y4s = conv_ops.conv_bias_act(x, w, b, 1, 'relu'), conv_ops.conv_bias_act(xs, ws, bs, 1, 'relu')
             y4p = conv_ops.conv_bias_act((x[:, :64].contiguous(), x[:, 64:].contiguous()), w, b, 1, 'relu')
         finally:
-            conv_ops.set_winograd_tile(prev)
+            conv_ops.set_winograd_tile(before)
     assert torch.equal(y4s, y2s)                                  # C = K = 64: stays on F(2x2, 3x3)
     assert not torch.equal(y4, y2) and torch.equal(y4, _run([x], w, b, 'relu')) and torch.equal(y4p, y4)
     assert float((y4 - y2).abs().max()) <= 1e-4 * float(y2.abs().max())
@@ -216,12 +218,13 @@ def test_full_width_forward_with_the_4x4_tile_matches_cpu_oracle(monkeypatch):
     with torch.no_grad():
         ref = tai_oracle.tai_forward(sd, 1, 5, 51, 5, P, Fo)
         m.to('cuda:0').eval()
-        o2 = m(5, P.cuda(), Fo.cuda())
-        prev = conv_ops.set_winograd_tile(4)
+        before = conv_ops.set_winograd_tile(2)
         try:
+            o2 = m(5, P.cuda(), Fo.cuda())
+            conv_ops.set_winograd_tile(4)
             o4 = m(5, P.cuda(), Fo.cuda())
         finally:
-            conv_ops.set_winograd_tile(prev)
+            conv_ops.set_winograd_tile(before)
     for k in ('pred', 'pred_forward', 'pred_backward', 'interp_net_outputs_1', 'interp_net_outputs_2'):
         scale = float(ref[k].abs().max())
         e4, e2 = float((o4[k].cpu() - ref[k]).abs().max()), float((o2[k].cpu() - ref[k]).abs().max())

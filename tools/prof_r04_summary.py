@@ -144,13 +144,14 @@ json.dump(pmc, open(os.path.join(res_dir, 'sepconv_fwd_pmc.json'), 'w'), indent=
 # ---- Winograd kernel: per template instance and grid, MFMA-busy share of the SIMD cycles
 tr = collections.defaultdict(list)
 for r in trace_rows('bench_trace'):
-    if 'wino::conv3x3' in r['Kernel_Name']:
+    if 'wino::conv3x3' in r['Kernel_Name'] or 'wino43::conv3x3' in r['Kernel_Name']:
         tr[(short(r['Kernel_Name']), int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0))].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-sq = counters('bench_sq', 'wino::conv3x3')
-lds = counters('bench_lds', 'wino::conv3x3')
+sq = counters('bench_sq', 'wino::conv3x3'); sq.update(counters('bench_sq', 'wino43::conv3x3'))
+lds = counters('bench_lds', 'wino::conv3x3'); lds.update(counters('bench_lds', 'wino43::conv3x3'))
 lines = ['rocprofv3 of `%s` (r04): the Winograd convolution kernel per template instance and grid' % CMD,
          'MFMA share = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): the fraction of SIMD-cycles in which the MFMA pipe was busy',
          '(padded channels included: K = 51 runs as 64, C = 51 as 56); us = kernel-trace mean; counters from the serialised --pmc pass',
+         'wino43::conv3x3<ACT, W8, EPI> = the F(4x4, 3x3) kernel on the wide layers (8 waves per workgroup: 1024 SIMDs x cycles as well)',
          '', '%-44s %9s %6s %9s %11s %10s %9s' % ('kernel<ACT,DBG,SKIP,PARTS,TALL,EPI>', 'grid', 'n', 'mean us', 'MFMA share', 'LDS confl', 'wait any')]
 tot_busy = tot_cyc = 0.0
 for key in sorted(tr, key=lambda k: -sum(tr[k])):
@@ -164,7 +165,7 @@ for key in sorted(tr, key=lambda k: -sum(tr[k])):
     lines.append('%-44s %9d %6d %9.1f %11.3f %10.3f %9.3f' % (k.replace('void wino::', '')[:44], g, len(tr[key]), mean(tr[key]), share, confl, wait))
 if tot_cyc:
     lines.append('all dispatches: MFMA share %.3f of the SIMD-cycles' % (tot_busy / tot_cyc))
-wrows = [r for r in rows if 'wino::conv3x3' in r['Name']]
+wrows = [r for r in rows if 'wino::conv3x3' in r['Name'] or 'wino43::conv3x3' in r['Name']]
 lines.append('kernel-trace: %d dispatches, %.2f ms in total = %.1f %% of the GPU time of the run' % (
     sum(int(r['Calls']) for r in wrows), sum(float(r['TotalDurationNs']) for r in wrows) / 1e6, sum(float(r['Percentage']) for r in wrows)))
 open(os.path.join(res_dir, 'r04_wino_conv_pmc.txt'), 'w').write('\n'.join(lines) + '\n')

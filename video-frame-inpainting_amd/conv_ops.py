@@ -66,18 +66,19 @@ def get_winograd_arithmetic():
     return [k for k, v in WINOGRAD_ARITHMETICS.items() if v == mode][0]
 
 
-_WINO_TILE = [2]
+_WINO_TILE = [4]
 WINO43_MIN_CHANNELS = 128        # F(4x4, 3x3) only where both C and K are at least this (profiles/r04_wino_f43_study.txt: parity-neutral there)
 WINO43_MIN_WORKGROUPS = 400      # ... and where its 64-channel x 32-tile workgroups fill the chip at least ~1.6 times over
 
 
 def set_winograd_tile(m):
-    """Output tile of the Winograd 3x3 convolutions of the inference path: 2 (default: F(2x2, 3x3), csrc/wino_conv.hip.inc, every layer) or
-    4 (opt-in: F(4x4, 3x3), csrc/wino43_conv.hip.inc, on the plain and channel-part layers with C >= 128 and K >= 128 and enough
-    workgroups -- 1.78x fewer MFMAs at ~7x the fp32 rounding error per layer; restricted to those layers the forward's end-to-end error
-    is unchanged, profiles/r04_wino_f43_study.txt).  Layers with a fused second output (max pool, unpool + add), the displaced-read
-    5x5 / 7x7 layers and everything under autograd stay on F(2x2, 3x3).  A hipGraph captured before the switch keeps replaying what it
-    captured.  Returns the previous value."""
+    """Output tile of the Winograd 3x3 convolutions of the inference path: 4 (default since the end of round 4): F(4x4, 3x3),
+    csrc/wino43_conv.hip.inc, on the layers with C >= 128 and K >= 128 and enough workgroups -- 1.78x fewer MFMAs, fp32 operands on the
+    fp32 MFMA as everywhere else; its rounding error is ~7x F(2x2, 3x3)'s per layer, and restricted to those layers the forward's
+    end-to-end error against the CPU oracle is unchanged on every config (profiles/r04_wino_f43_study.txt, r04_wino43_default_parity.txt)
+    -- and F(2x2, 3x3), csrc/wino_conv.hip.inc, on every other layer; or 2: F(2x2, 3x3) on every layer (the arithmetic of rounds 1-3).
+    The displaced-read 5x5 / 7x7 layers and everything under autograd are F(2x2, 3x3) either way.  A hipGraph captured before a switch
+    keeps replaying what it captured.  Returns the previous value."""
     if m not in (2, 4):
         raise ValueError(m)
     prev, _WINO_TILE[0] = _WINO_TILE[0], m
@@ -298,7 +299,7 @@ def conv_bias_unpool_add(x, weight, bias, padding, addx, keep_plain=True):
     y = torch.empty((N, Co, H, W), dtype=torch.float32, device=x0.device)
     y2 = torch.empty_like(y) if keep_plain else None
     ptrs = (ctypes.c_void_p * len(parts))(*[q.data_ptr() for q in parts])
-    if _wino43_ok(N, Ci, Co, H, W, len(parts)):              # opt-in: F(4x4, 3x3) (set_winograd_tile): a tile holds four unpooling cells
+    if _wino43_ok(N, Ci, Co, H, W, len(parts)):              # wide layer: F(4x4, 3x3) (set_winograd_tile): a tile holds four unpooling cells
         U = _wino43_weights(weight, False)
         with torch.cuda.device(x0.device):
             _native.check(L.tai_conv3x3_wino43_forward_ex(ptrs, len(parts), U.data_ptr(), bias.data_ptr(), y.data_ptr(), None, addx.data_ptr(),
@@ -759,7 +760,7 @@ def conv_bias_act_maxpool(x, weight, bias, padding, act):
                     _native.check(L.tai_conv_cin1_forward_maxpool(x.data_ptr(), weight.contiguous().data_ptr(), bias.data_ptr(),
                                                                   y.data_ptr(), yp.data_ptr(), N, Co, H, W, kh, _ACT[act], stream),
                                   'tai_conv_cin1_forward_maxpool')
-                elif kh == kw == 3 and padding == 1 and _wino43_ok(N, Ci, Co, H, W):      # opt-in: F(4x4, 3x3): a tile is four pooling windows
+                elif kh == kw == 3 and padding == 1 and _wino43_ok(N, Ci, Co, H, W):      # wide layer: F(4x4, 3x3): a tile is four pooling windows
                     U = _wino43_weights(weight, False)
                     xs = (ctypes.c_void_p * 1)(x.data_ptr())
                     _native.check(L.tai_conv3x3_wino43_forward_ex(xs, 1, U.data_ptr(), bias.data_ptr(), y.data_ptr(), yp.data_ptr(), None, None,
@@ -816,7 +817,7 @@ def _conv_bias_act(x, weight, bias, padding, act, transposed, out):
         y = out if _usable_out(out, (N, Co, H, W), x0) else torch.empty((N, Co, H, W), dtype=x0.dtype, device=x0.device)
         ptrs = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
         with torch.cuda.device(x0.device):
-            if _wino43_ok(N, Ci, Co, H, W, len(parts)):      # opt-in: F(4x4, 3x3) (set_winograd_tile)
+            if _wino43_ok(N, Ci, Co, H, W, len(parts)):      # wide layer: F(4x4, 3x3) (set_winograd_tile)
                 U = _wino43_weights(weight, transposed)
                 _native.check(L.tai_conv3x3_wino43_forward_parts(ptrs, len(parts), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci,
                                                                  Co, H, W, _ACT[act], torch.cuda.current_stream(x0.device).cuda_stream),
@@ -877,7 +878,7 @@ def _conv_bias_act(x, weight, bias, padding, act, transposed, out):
         x = x.contiguous()
         y = out if _usable_out(out, (N, Co, H, W), x) else torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device)
         with torch.cuda.device(x.device):
-            if _wino43_ok(N, Ci, Co, H, W):                  # opt-in: F(4x4, 3x3) (set_winograd_tile)
+            if _wino43_ok(N, Ci, Co, H, W):                  # wide layer: F(4x4, 3x3) (set_winograd_tile)
                 U = _wino43_weights(weight, transposed)
                 _native.check(L.tai_conv3x3_wino43_forward(x.data_ptr(), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci, Co,
                                                            H, W, _ACT[act], stream), 'tai_conv3x3_wino43_forward')

@@ -36,10 +36,10 @@ class BaseOptions(object):
                             'parity statement is made on); bf16x3 = opt-in split bf16 (three bf16 terms per operand, six products, '
                             'fp32 accumulation: error at or below the fp32 form, 3-25 %% faster per layer)')
 
-        g.add_argument('--winograd_tile', type=int, default=2, choices=[2, 4],
-                       help='(this build) output tile of the 3x3 Winograd convolutions at inference: 2 = F(2x2,3x3) on every layer (default); '
-                            '4 = opt-in F(4x4,3x3) on the layers with at least 128 input and output channels (1.78x fewer MFMAs there; the '
-                            "forward's end-to-end error is unchanged, ~3 %% faster at 32 clips)")
+        g.add_argument('--winograd_tile', type=int, default=4, choices=[2, 4],
+                       help='(this build) output tile of the 3x3 Winograd convolutions at inference: 4 = F(4x4,3x3) on the layers with at least '
+                            "128 input and output channels (default: 1.78x fewer MFMAs there, the forward's end-to-end error unchanged, ~3 %% "
+                            'faster at 32 clips) and F(2x2,3x3) elsewhere; 2 = F(2x2,3x3) on every layer')
 
     def parse(self, args=None, allow_unknown=False, require_gpu=True):
         if allow_unknown:
