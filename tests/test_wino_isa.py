@@ -192,3 +192,25 @@ def test_split_kernel_counted_waits_registers_and_mfma_count(device_asm, parts, 
     text = device_asm[device_asm.find(prefix):]
     meta = text[text.find('.amdhsa_kernel'):text.find('.end_amdhsa_kernel')]
     assert re.search(r'\.amdhsa_accum_offset\s+128', meta) and re.search(r'\.amdhsa_next_free_vgpr\s+256', meta), meta[:400]
+
+
+def test_wino43_kernel_has_no_spills_and_keeps_its_mfma_count(device_asm):
+    """The F(4x4, 3x3) kernel (csrc/wino43_conv.hip.inc): its eight-wave form runs at 256 registers per wave with 144 of them accumulators and
+    has none to spare -- a draft of the patch transform on register pairs spilled 31, put scratch loads (vector-memory traffic the asm loads'
+    own wait counting does not expect) into the chunk loop and produced wrong results (profiles/r04_wino43_prototype.txt).  Every instantiation:
+    next to no scratch instruction (the draft had 60) and none between the MFMAs of a chunk; 36 (eight waves) or 72 (four) MFMAs per chunk
+    and nothing else on the matrix pipe; nine weight DMAs per chunk."""
+    found = 0
+    for name, lines in _kernel_bodies(device_asm, '_ZN6wino437conv3x3I'):
+        found += 1
+        w8 = 'Lb1E' in name
+        scratch = sum(1 for l in lines if re.search(r'\bscratch_(load|store)', l))
+        assert scratch <= 12, (name, scratch)                     # (one to four registers per instantiation, around the prologue / epilogue)
+        mf = [n for n, l in enumerate(lines) if re.search(r'\bv_mfma_', l)]
+        assert not any(re.search(r'\bscratch_(load|store)', l) for l in lines[mf[0]:mf[-1] + 1]), name      # none between the chunk's MFMAs
+        mfma = sum(1 for l in lines if re.search(r'\bv_mfma_f32_16x16x4_f32\b', l))
+        assert mfma == (36 if w8 else 72), (name, mfma)
+        assert not any(re.search(r'\bv_mfma_(?!f32_16x16x4_f32\b)', l) for l in lines), name
+        dma = sum(1 for l in lines if 'global_load_lds_dwordx4' in l)
+        assert dma == 18, (name, dma)          # nine in the prologue, nine in the chunk loop
+    assert found >= 8              # <ACT 0..2> x <4 | 8 waves> plain, + the pooled / unpool-add epilogues of the eight-wave form
