@@ -207,7 +207,12 @@ def test_wino43_kernel_has_no_spills_and_keeps_its_mfma_count(device_asm):
         scratch = sum(1 for l in lines if re.search(r'\bscratch_(load|store)', l))
         assert scratch <= 12, (name, scratch)                     # (one to four registers per instantiation, around the prologue / epilogue)
         mf = [n for n, l in enumerate(lines) if re.search(r'\bv_mfma_', l)]
-        assert not any(re.search(r'\bscratch_(load|store)', l) for l in lines[mf[0]:mf[-1] + 1]), name      # none between the chunk's MFMAs
+        # none between the chunk's first MFMA and the s_waitcnt vmcnt(0) behind its last: the patch's outer values are loaded by asm
+        # statements in there, whose outputs the compiler takes for valid at once -- a spill of one of them before that wait would store a
+        # register the load has not written yet
+        end = next(n for n in range(mf[-1], len(lines)) if re.search(r's_waitcnt\s+vmcnt\(0\)', lines[n]))
+        assert end - mf[-1] <= 6, (name, end - mf[-1])
+        assert not any(re.search(r'\bscratch_(load|store)', l) for l in lines[mf[0]:end + 1]), name
         mfma = sum(1 for l in lines if re.search(r'\bv_mfma_f32_16x16x4_f32\b', l))
         assert mfma == (36 if w8 else 72), (name, mfma)
         assert not any(re.search(r'\bv_mfma_(?!f32_16x16x4_f32\b)', l) for l in lines), name
