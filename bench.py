@@ -54,6 +54,7 @@ def _imports():
     from video_frame_inpainting_amd import _native, metrics, parallel, synthetic
     from video_frame_inpainting_amd import separable_convolution as sc
     from video_frame_inpainting_amd.graph import GraphedForward
+    vfi.configure_miopen()       # FAST find mode unless set; under torch.distributed.run one MIOpen find-db / kernel cache per rank
 
 
 def log(msg):

@@ -60,8 +60,15 @@ class DiscriminatorState(object):
             self.uses.append((key + '.weight', W))
         return W
 
-    def forward(self, frames, track=False, bias_leaves=None):
-        """SNDiscriminator.forward, :140-159: frames [B, T, C, H, W] -> logits [B, T - window + 1]."""
+    def forward(self, frames, track=False, bias_leaves=None, masks=None):
+        """SNDiscriminator.forward, :140-159: frames [B, T, C, H, W] -> logits [B, T - window + 1].
+
+        ``masks`` ({(window, layer key): bool [B, Co, H', W']}, optional): the side of LeakyReLU's kink each pre-activation is
+        taken to lie on, given from outside instead of read from this run's own rounding.  The gradient is discontinuous there:
+        ONE pre-activation of conv_layers.0 that rounds to the other side of zero moves that layer's weight gradient by 3e-3 of its
+        maximum (tests/test_train_oracle_cpu.py pins this with an fp64 run), so a gradient comparison between two fp32
+        implementations is only well-posed once both differentiate the same piecewise-linear function.  Values are unaffected to
+        rounding (the elements concerned are at rounding distance from zero)."""
         B, T, C, H, W = frames.shape
         outs = []
         for t0 in range(T - self.window_size + 1):
@@ -69,7 +76,8 @@ class DiscriminatorState(object):
             for key in SN_CONV_KEYS:
                 w = self._renormalised(key, self.Ip, track)
                 b = bias_leaves[key + '.bias'] if bias_leaves is not None else self.sd[key + '.bias']
-                x = F.leaky_relu(F.conv2d(x, w, b, stride=2, padding=1), 0.2)
+                y = F.conv2d(x, w, b, stride=2, padding=1)
+                x = F.leaky_relu(y, 0.2) if masks is None else torch.where(masks[(t0, key)], y, 0.2 * y)
             w = self._renormalised('linear_layer', 1, track)                     # SNLinear(..., Ip=1), :136
             b = bias_leaves['linear_layer.bias'] if bias_leaves is not None else self.sd['linear_layer.bias']
             outs.append(F.linear(x.reshape(B, -1), w, b))
@@ -95,10 +103,10 @@ def _time_major_01(x):
     return tai_oracle.inverse_transform(x.permute(1, 0, 2, 3, 4).contiguous().view(-1, c, H, W))
 
 
-def training_step(gen_sd, disc, c_dim, num_block, ks, P, GT, Fo, alpha, beta, grad_keys):
-    """One G-then-D step without the optimiser updates.  ``gen_sd``: generator state dict (reference schema);
-    ``disc``: DiscriminatorState (mutated).  Returns (losses dict, {generator key: grad} for ``grad_keys``,
-    {discriminator key: grad} for every discriminator parameter, outputs dict)."""
+def generator_leg(gen_sd, disc, c_dim, num_block, ks, P, GT, Fo, alpha, beta, grad_keys):
+    """The G half of the step (forward_train + the generator loss and its gradients; environments.py:173-176, :358-379,
+    :429-453).  ``disc`` is mutated by the one discriminator evaluation inside the loss.  Returns (loss terms as tensors,
+    {generator key: grad}, outputs dict, fake = cat[P, pred, F] detached)."""
     K, T, Fn = P.shape[1], GT.shape[1], Fo.shape[1]
     sd = {k: v.detach().clone() for k, v in gen_sd.items()}
     for k in grad_keys:
@@ -119,15 +127,22 @@ def training_step(gen_sd, disc, c_dim, num_block, ks, P, GT, Fo, alpha, beta, gr
         terms['G_Lp_forward'] + terms['G_Lp_backward'] + terms['G_gdl_forward'] + terms['G_gdl_backward'])
     terms['G_loss'] = loss_G
     g_grads = dict(zip(grad_keys, torch.autograd.grad(loss_G, [sd[k] for k in grad_keys])))
+    return {k: v.detach() for k, v in terms.items()}, g_grads, {k: v.detach() for k, v in out.items()}, fake.detach()
 
-    # ---- discriminator loss (environments.py:326-345), after the G update in the reference's order (:348-355)
+
+def discriminator_leg(disc, fake, P, GT, Fo, masks_fake=None, masks_real=None):
+    """The D half (environments.py:326-345), after the G half in the reference's order (:348-355): D(fake.detach()) against the
+    window labels of :308-323, D(real) against ones.  ``masks_*``: see DiscriminatorState.forward.  Returns (loss terms,
+    {discriminator key: grad} for every discriminator parameter)."""
+    K, T, Fn = P.shape[1], GT.shape[1], Fo.shape[1]
+    terms = {}
     disc.uses = []
     bias_leaves = {k: v.clone().requires_grad_(True) for k, v in disc.sd.items() if k.endswith('.bias')}
-    hf = disc.forward(fake.detach(), track=True, bias_leaves=bias_leaves)
-    labels = fake_labels(K, T, Fn, disc.window_size).view(1, -1).expand(fake.size(0), -1)
+    hf = disc.forward(fake.detach(), track=True, bias_leaves=bias_leaves, masks=masks_fake)
+    labels = fake_labels(K, T, Fn, disc.window_size).view(1, -1).expand(fake.size(0), -1).to(hf.dtype)
     terms['D_fake'] = F.binary_cross_entropy_with_logits(hf, labels)
     real = torch.cat([P, GT, Fo], dim=1)
-    hr = disc.forward(real, track=True, bias_leaves=bias_leaves)
+    hr = disc.forward(real, track=True, bias_leaves=bias_leaves, masks=masks_real)
     terms['D_real'] = F.binary_cross_entropy_with_logits(hr, torch.ones_like(hr))
     loss_D = terms['D_fake'] + terms['D_real']
     leaves = [w for _, w in disc.uses] + list(bias_leaves.values())
@@ -137,5 +152,15 @@ def training_step(gen_sd, disc, c_dim, num_block, ks, P, GT, Fo, alpha, beta, gr
         d_grads[key] = d_grads.get(key, 0) + g
     for key, g in zip(bias_leaves, grads[len(disc.uses):]):
         d_grads[key] = g
-    losses = {k: float(v.detach()) for k, v in terms.items()}
-    return losses, g_grads, d_grads, {k: v.detach() for k, v in out.items()}
+    return {k: v.detach() for k, v in terms.items()}, d_grads
+
+
+def training_step(gen_sd, disc, c_dim, num_block, ks, P, GT, Fo, alpha, beta, grad_keys, masks_fake=None, masks_real=None):
+    """One G-then-D step without the optimiser updates.  ``gen_sd``: generator state dict (reference schema);
+    ``disc``: DiscriminatorState (mutated).  Returns (losses dict, {generator key: grad} for ``grad_keys``,
+    {discriminator key: grad} for every discriminator parameter, outputs dict)."""
+    terms, g_grads, out, fake = generator_leg(gen_sd, disc, c_dim, num_block, ks, P, GT, Fo, alpha, beta, grad_keys)
+    d_terms, d_grads = discriminator_leg(disc, fake, P, GT, Fo, masks_fake, masks_real)
+    terms.update(d_terms)
+    losses = {k: float(v) for k, v in terms.items()}
+    return losses, g_grads, d_grads, out

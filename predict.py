@@ -40,6 +40,7 @@ def save_video_frames(video, image_root_dir, image_name_prefix, counter_start=0)
 
 def main(args=None):
     opt = TestOptions().parse(args, allow_unknown=True)
+    vfi.configure_miopen()
     rank, world, local_rank = parallel.init_from_env()
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)

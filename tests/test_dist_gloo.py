@@ -135,3 +135,43 @@ def test_training_environment_keeps_replicas_identical(tmp_path):
     b, ktf_b = torch.load(tmp_path / 'env_rank1.pt')
     assert ktf_a == ktf_b
     assert torch.equal(a, b)
+
+
+def _shard_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend='gloo')
+    import video_frame_inpainting_amd as vfi
+    from video_frame_inpainting_amd import synthetic
+    torch.manual_seed(50 + rank)                      # replicas start different; the broadcast makes them rank 0's
+    model = vfi.MCNetFillInModel(4, 1, 3).eval()      # the clip-sharded inference path without the GPU-only sepconv
+    parallel.broadcast_module_state(model)
+    n_clips = 5                                       # not divisible by 2: the shards differ in size
+    clips = torch.from_numpy(synthetic.make_clips(n_clips, 8, 1, 32, 32, 321))
+    mine = parallel.shard_slice(n_clips, rank, world)
+    with torch.no_grad():
+        out = model(2, clips[mine, :3], clips[mine, 5:])['pred']
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (mine.start, mine.stop, out.numpy()))
+    if rank == 0:
+        with torch.no_grad():
+            whole = model(2, clips[:, :3], clips[:, 5:])['pred'].numpy()
+        np.save(os.path.join(out_dir, 'whole.npy'), whole)
+        covered = []
+        union = np.full_like(whole, np.nan)
+        for a, b, o in gathered:
+            covered += list(range(a, b))
+            union[a:b] = o
+        np.save(os.path.join(out_dir, 'union.npy'), union)
+        np.save(os.path.join(out_dir, 'covered.npy'), np.array(covered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_union_of_rank_shards_equals_the_single_rank_forward(tmp_path):
+    """Inference shards clips over ranks with no collective on the data path (parallel.shard_slice, predict.py:57): the union of the
+    ranks' outputs is the whole batch's forward -- every clip exactly once, values equal (clips are independent: no batch statistic)."""
+    mp.spawn(_shard_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    whole, union = np.load(tmp_path / 'whole.npy'), np.load(tmp_path / 'union.npy')
+    assert sorted(np.load(tmp_path / 'covered.npy').tolist()) == list(range(5))
+    assert np.isfinite(union).all() and float(np.abs(whole).max()) > 0.01
+    np.testing.assert_allclose(union, whole, rtol=0, atol=1e-6)

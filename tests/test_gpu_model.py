@@ -78,7 +78,28 @@ def test_cfg1_shape_matches_cpu_oracle_and_psnr_parity():
     _assert_matches_oracle(out, ref, GT, 'cfg1 shape')
 
 
-def test_full_width_tai_gray_matches_cpu_oracle():
+def _at_the_timed_batch_dispatch(monkeypatch, scale, m, T, P, Fo, ref, GT, name, rel_tol=REL_TOL):
+    """The same clips once more with every convolution routed as in the timed batch of the config (tests/conftest.py: DispatchAt;
+    ``scale`` x these clips), with F(4x4, 3x3) on the wide layers (the default) and with F(2x2, 3x3) everywhere: the wide
+    low-resolution layers that a 1-2 clip batch hands to MIOpen then run the in-tree kernels the bench times.  No ATen convolution
+    may be left in the forward."""
+    from conftest import DispatchAt, miopen_convolutions
+    from video_frame_inpainting_amd import conv_ops
+    with monkeypatch.context() as mp:
+        d = DispatchAt(mp, scale)
+        for tile in (4, 2):
+            prev = conv_ops.set_winograd_tile(tile)
+            try:
+                with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU], record_shapes=True) as prof:
+                    out = m(T, P.to(DEV), Fo.to(DEV))
+            finally:
+                conv_ops.set_winograd_tile(prev)
+            _assert_matches_oracle(out, ref, GT, '%s, dispatch of %d x the clips, Winograd tile %d' % (name, scale, tile), rel_tol=rel_tol)
+            assert not miopen_convolutions(prof), miopen_convolutions(prof)[:4]
+        assert d.routes['wino43'] > 0, d.routes
+
+
+def test_full_width_tai_gray_matches_cpu_oracle(monkeypatch):
     """The model BASELINE's headline is quoted on -- TAI_gray, gf_dim 64, 128x128, K=F=T=5 -- against the CPU oracle on two
     clips: every 3x3 layer runs on the Winograd-MFMA kernels at their production shapes (the reduced-width tests fall
     below conv_ops.WINO_MIN_WORKGROUPS on most layers), the 5x5 / 7x7 layers on the shifted-stack path."""
@@ -93,9 +114,10 @@ def test_full_width_tai_gray_matches_cpu_oracle():
         _assert_matches_oracle(out, ref, GT, 'full width, eager')
         g = GraphedForward(m, 5, P.to(DEV), Fo.to(DEV))
         _assert_matches_oracle(g(), ref, GT, 'full width, hipGraph replay')
+        _at_the_timed_batch_dispatch(monkeypatch, 16, m, 5, P, Fo, ref, GT, 'configs[1]')
 
 
-def test_full_width_tai_color_matches_cpu_oracle():
+def test_full_width_tai_color_matches_cpu_oracle(monkeypatch):
     """configs[3]'s model -- create_model('TAI_color') = TAIFillInModel(64, 3, 3, 51, num_block=4) (create_model.py:29-30),
     256x256 BGR, K = F = 3, T = 5 -- at its real width against the CPU oracle on one clip: the 256^2 Winograd layer
     shapes, the three-channel sepconv kernel (sepconv_forward_asm_c3) at [5,3,256,256], the decoder that never injects
@@ -111,9 +133,10 @@ def test_full_width_tai_color_matches_cpu_oracle():
         _assert_matches_oracle(out, ref, GT, 'TAI_color full width, eager')
         g = GraphedForward(m, 5, P.to(DEV), Fo.to(DEV))
         _assert_matches_oracle(g(), ref, GT, 'TAI_color full width, hipGraph replay')
+        _at_the_timed_batch_dispatch(monkeypatch, 16, m, 5, P, Fo, ref, GT, 'configs[3]')
 
 
-def test_full_width_tai_gray_long_gap_matches_cpu_oracle():
+def test_full_width_tai_gray_long_gap_matches_cpu_oracle(monkeypatch):
     """configs[4]: TAI_gray at full width with T = 10 middle frames (alt_T), K = F = 5, one clip."""
     m = synthetic.seeded_init(vfi.create_model('TAI_gray'), 0)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
@@ -127,6 +150,7 @@ def test_full_width_tai_gray_long_gap_matches_cpu_oracle():
         # ten recurrent MC-Net steps instead of five: the tanh-bounded predictions drift to 0.8-1.0e-4 of their maximum on some
         # clips (bench.py's configs[4] check) -- inside SURVEY.md 8d's 2e-4 bound for the full model, which is the bound used here
         _assert_matches_oracle(out, ref, GT, 'TAI_gray T=10 full width', rel_tol=2e-4)
+        _at_the_timed_batch_dispatch(monkeypatch, 32, m, 10, P, Fo, ref, GT, 'configs[4]', rel_tol=2e-4)
 
 
 def test_headline_forward_is_bit_reproducible():

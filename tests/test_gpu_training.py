@@ -26,7 +26,8 @@ GRAD_KEYS = ('generator.motion_enc.dyn_conv1.0.weight',      # first convolution
              'kernelnet.moduleConv.0.0.weight', 'kernelnet.moduleUpsample.3.1.weight',
              'kernelnet.moduleVertical1.7.weight', 'kernelnet.moduleHorizontal2.7.bias')
 LOSS_RTOL = 2e-4          # loss terms, relative
-GRAD_RTOL = 5e-3          # max |g_gpu - g_oracle| <= GRAD_RTOL * max |g_oracle| per parameter (measured: <= 3.3e-3, profiles/r02_training_parity.txt)
+GRAD_RTOL = 5e-3          # generator: max |g_gpu - g_oracle| <= GRAD_RTOL * max |g_oracle| per parameter
+D_GRAD_RTOL = 5e-3        # discriminator (measured: <= 3.3e-3, profiles/r02_training_parity.txt)
 
 
 @pytest.fixture(autouse=True)
@@ -50,62 +51,170 @@ def _seeded_env(tmp_path, gf_dim, kf_dim, df_dim, K, T, F, H, W):
     return env, u
 
 
-def _step_and_compare(tmp_path, gf_dim, kf_dim, df_dim, B, K=5, T=5, F=5, H=128, W=128):
+_ORACLE = {}
+
+
+def _oracle_generator_leg(key, gen_sd, disc_sd, u, P, GT, Fo):
+    """The CPU oracle's G half for one test geometry, computed once per process (seeded inputs: the same key means the same step):
+    (loss terms, generator gradients, fake clip, the discriminator's weights and u vectors after the evaluation inside the G loss)."""
+    if key not in _ORACLE:
+        disc = train_oracle.DiscriminatorState(disc_sd, u, IP, DISC_T)
+        terms, g_ref, _, fake = train_oracle.generator_leg(gen_sd, disc, 1, 5, 51, P, GT, Fo, ALPHA, BETA, list(GRAD_KEYS))
+        _ORACLE[key] = (terms, g_ref, fake, {k: v.clone() for k, v in disc.sd.items()}, {k: v.clone() for k, v in disc.u.items()})
+    return _ORACLE[key]
+
+
+class _KinkSides(object):
+    """Records, for every discriminator evaluation of the product, which side of LeakyReLU's kink each pre-activation fell on
+    (the sign of the layer's output: LeakyReLU keeps it).  The oracle's D half then differentiates the same piecewise-linear
+    function (train_oracle.DiscriminatorState.forward, ``masks``): one element of conv_layers.0 at rounding distance from zero
+    otherwise decides 3e-3 of that layer's weight gradient (tests/test_train_oracle_cpu.py)."""
+
+    def __init__(self, monkeypatch):
+        from video_frame_inpainting_amd import sn_discriminator as snd
+        self.layers = []
+        orig = snd._WindowScaledConvLReLU.apply
+
+        def spy(*args):
+            y = orig(*args)
+            self.layers.append((y.detach() > 0).cpu())
+            return y
+        monkeypatch.setattr(snd._WindowScaledConvLReLU, 'apply', staticmethod(spy))
+
+    def masks_of_call(self, call, B):
+        """{(window, layer key): bool [B, Co, H, W]} of the ``call``-th discriminator evaluation (4 layers each, windows along the batch)."""
+        out = {}
+        for li, key in enumerate(train_oracle.SN_CONV_KEYS):
+            m = self.layers[4 * call + li]
+            for t0 in range(m.shape[0] // B):
+                out[(t0, key)] = m[t0 * B:(t0 + 1) * B]
+        return out
+
+
+def _step_and_compare(tmp_path, monkeypatch, gf_dim, kf_dim, df_dim, B, K=5, T=5, F=5, H=128, W=128, profile=False, tag=''):
     env, u = _seeded_env(tmp_path, gf_dim, kf_dim, df_dim, K, T, F, H, W)
     gen_sd = {k: v.detach().cpu().clone() for k, v in env.generator.state_dict().items()}
-    disc = train_oracle.DiscriminatorState({k: v.detach().cpu() for k, v in env.discriminator.state_dict().items()}, u, IP, DISC_T)
+    disc_sd = {k: v.detach().cpu().clone() for k, v in env.discriminator.state_dict().items()}
     clips = torch.from_numpy(synthetic.make_clips(B, K + T + F, 1, H, W, synthetic.SEEDS['cfg3']))
     P, GT, Fo = synthetic.split_clip(clips, K, T, F)
+    sides = _KinkSides(monkeypatch)
 
     # the product: the reference's step order (environments.py:348-355) without the two optimiser updates
-    env.set_train_inputs(P, Fo, GT)
-    env.K, env.T, env.F = K, T, F
-    env.train()
-    env.forward_train()
-    env.optimizer_G.zero_grad()
-    env.compute_loss_G()
-    env.loss_G.backward()
-    g_gpu = {k: p.grad.detach().cpu().clone() for k, p in env.generator.named_parameters() if k in GRAD_KEYS}
-    env.optimizer_D.zero_grad()
-    env.compute_loss_D()
-    env.loss_D.backward()
-    d_gpu = {k: p.grad.detach().cpu().clone() for k, p in env.discriminator.named_parameters()}
+    import contextlib
+    prof = torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU], record_shapes=True) if profile \
+        else contextlib.nullcontext()
+    with prof:
+        env.set_train_inputs(P, Fo, GT)
+        env.K, env.T, env.F = K, T, F
+        env.train()
+        env.forward_train()
+        env.optimizer_G.zero_grad()
+        env.compute_loss_G()
+        env.loss_G.backward()
+        g_gpu = {k: p.grad.detach().cpu().clone() for k, p in env.generator.named_parameters() if k in GRAD_KEYS}
+        env.optimizer_D.zero_grad()
+        env.compute_loss_D()
+        env.loss_D.backward()
+        d_gpu = {k: p.grad.detach().cpu().clone() for k, p in env.discriminator.named_parameters()}
     errs = env.get_current_errors()
+    assert len(sides.layers) == 12, len(sides.layers)           # D(fake) in the G loss, D(fake.detach()), D(real): 4 layers each
 
-    losses, g_ref, d_ref, out_ref = train_oracle.training_step(gen_sd, disc, 1, 5, 51, P, GT, Fo, ALPHA, BETA, list(GRAD_KEYS))
+    terms, g_ref, fake, sd1, u1 = _oracle_generator_leg((gf_dim, kf_dim, df_dim, B, K, T, F, H, W), gen_sd, disc_sd, u, P, GT, Fo)
+    disc = train_oracle.DiscriminatorState(sd1, u1, IP, DISC_T)
+    d_terms, d_ref = train_oracle.discriminator_leg(disc, fake, P, GT, Fo, sides.masks_of_call(1, B), sides.masks_of_call(2, B))
+    # ... and with the oracle's own rounding deciding the sides, for the record (what the bound had to absorb before)
+    disc_own = train_oracle.DiscriminatorState(sd1, u1, IP, DISC_T)
+    _, d_own = train_oracle.discriminator_leg(disc_own, fake, P, GT, Fo)
+    losses = {k: float(v) for k, v in list(terms.items()) + list(d_terms.items())}
 
-    report = []
+    report = ['== %s gf_dim %d B %d K %d T %d F %d %dx%d' % (tag, gf_dim, B, K, T, F, H, W)]
+    worst = {'G': 0.0, 'D': 0.0, 'D own sides': 0.0}
     for k in sorted(losses):
         rel = abs(errs[k] - losses[k]) / max(abs(losses[k]), 1e-12)
         report.append('%-16s gpu %.7g oracle %.7g rel %.2e' % (k, errs[k], losses[k], rel))
         assert rel <= LOSS_RTOL, report[-1]
         assert abs(losses[k]) > 1e-4, report[-1]                       # a vanishing term would make the check vacuous
-    for name, got, want in [(k, g_gpu[k], g_ref[k]) for k in GRAD_KEYS] + [('D.' + k, d_gpu[k], d_ref[k]) for k in sorted(d_ref)]:
-        scale = float(want.abs().max())
-        err = float((got - want).abs().max())
-        report.append('%-44s max|g| %.3e  err/max %.2e' % (name, scale, err / max(scale, 1e-30)))
+    for k in GRAD_KEYS:
+        scale = float(g_ref[k].abs().max())
+        err = float((g_gpu[k] - g_ref[k]).abs().max())
+        report.append('%-44s max|g| %.3e  err/max %.2e' % (k, scale, err / max(scale, 1e-30)))
         assert scale > 1e-7, report[-1]
+        worst['G'] = max(worst['G'], err / scale)
         assert err <= GRAD_RTOL * scale, report[-1]
+    for k in sorted(d_ref):
+        scale = float(d_ref[k].abs().max())
+        err = float((d_gpu[k] - d_ref[k]).abs().max())
+        own = float((d_gpu[k] - d_own[k]).abs().max())
+        report.append('%-44s max|g| %.3e  err/max %.2e   (oracle deciding the kink sides itself: %.2e)' %
+                      ('D.' + k, scale, err / max(scale, 1e-30), own / max(scale, 1e-30)))
+        assert scale > 1e-7, report[-1]
+        worst['D'], worst['D own sides'] = max(worst['D'], err / scale), max(worst['D own sides'], own / scale)
+        assert err <= D_GRAD_RTOL * scale, report[-1]
+    report.append('worst err/max: generator %.2e (bound %.0e)  discriminator %.2e (bound %.0e; %.2e with the oracle deciding the kink sides itself)'
+                  % (worst['G'], GRAD_RTOL, worst['D'], D_GRAD_RTOL, worst['D own sides']))
     # the discriminator's weights were renormalised 3 x 13 times in place on both sides: same end state
     for k, v in env.discriminator.state_dict().items():
         ref = disc.sd[k]
         assert float((v.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max()), k
     print('\n'.join(report))
+    if profile:
+        return errs, prof
     return errs
 
 
-def test_training_step_cfg3_geometry_reduced_width(tmp_path):
-    _step_and_compare(tmp_path, gf_dim=8, kf_dim=4, df_dim=8, B=2)
+def test_training_step_cfg3_geometry_reduced_width(tmp_path, monkeypatch):
+    _step_and_compare(tmp_path, monkeypatch, gf_dim=8, kf_dim=4, df_dim=8, B=2)
 
 
-def test_training_step_full_width(tmp_path):
+def test_training_step_full_width(tmp_path, monkeypatch):
     """TAI_gray as configs[2] trains it (gf_dim 64, kf_dim 32, df_dim 64), B = 2."""
-    _step_and_compare(tmp_path, gf_dim=64, kf_dim=32, df_dim=64, B=2)
+    _step_and_compare(tmp_path, monkeypatch, gf_dim=64, kf_dim=32, df_dim=64, B=2)
 
 
-def test_training_step_short_context_nonsquare(tmp_path):
+def test_training_step_full_width_at_the_32_clip_dispatch(tmp_path, monkeypatch, dispatch_at_32_clips):
+    """The same full-width B = 2 step with every convolution routed as at configs[2]'s 32 clips per GPU (tests/conftest.py:
+    DispatchAt): the ConvLSTM's 512 -> 1024 at 16 x 16, CombLayers, ContentEnc / DecCnn's 256-channel layers at 32 x 32, Residual 3 and
+    the kernel network's 8 x 8 / 4 x 4 layers run _WinoConv3x3 / _WinoConv3x3Parts / tai_conv3x3_wino_wrw where the default thresholds
+    send a 2-clip batch to MIOpen (conv_ops.WINO_MIN_WORKGROUPS).  Same oracle, same bounds; and no ATen convolution ran outside the
+    discriminator's four 4 x 4 stride-2 layers (environments.py:348-379, mcnet.py:259-294)."""
+    from conftest import miopen_convolutions
+    _, prof = _step_and_compare(tmp_path, monkeypatch, gf_dim=64, kf_dim=32, df_dim=64, B=2, profile=True, tag='32-clip dispatch')
+    convs = miopen_convolutions(prof)
+    outside = [c for c in convs if tuple(c[1][2 if 'backward' in c[0] else 1][-2:]) != (4, 4)]
+    assert convs and not outside, outside[:8]
+    r = dispatch_at_32_clips.routes
+    print('routes taken: %s; ATen convolutions (all 4 x 4, the discriminator): %d' % (r, len(convs)))
+    assert r['wino'] > 100
+
+
+def test_forward_train_of_32_clips_equals_the_2_clip_forward_at_its_dispatch(tmp_path, monkeypatch):
+    """Clips are independent (no batch statistics anywhere in the generator): the training-mode forward of clips [0:2] inside a
+    32-clip batch equals the forward of those two clips alone once the 2-clip batch takes the 32-clip batch's kernel routes -- which
+    ties the oracle comparison above (B = 2, forced routes) to the batch configs[2] trains on."""
+    from conftest import DispatchAt
+    K = T = F = 5
+    env, _ = _seeded_env(tmp_path, 64, 32, 64, K, T, F, 128, 128)
+    clips = torch.from_numpy(synthetic.make_clips(32, K + T + F, 1, 128, 128, synthetic.SEEDS['cfg3']))
+    P, GT, Fo = synthetic.split_clip(clips, K, T, F)
+    env.K, env.T, env.F = K, T, F
+    env.train()
+    env.set_train_inputs(P, Fo, GT)
+    env.forward_train()
+    big = {k: v[:2].detach().clone() for k, v in env.gen_output.items()}
+    env.gen_output = None
+    DispatchAt(monkeypatch, 16)
+    env.set_train_inputs(P[:2], Fo[:2], GT[:2])
+    env.forward_train()
+    for k, v in env.gen_output.items():
+        scale = float(big[k].abs().max())
+        err = float((v.detach() - big[k]).abs().max())
+        print('%-24s max %.3e  err/max %.2e' % (k, scale, err / scale))
+        assert scale > 0.05 and err <= 1e-5 * scale, (k, err, scale)
+
+
+def test_training_step_short_context_nonsquare(tmp_path, monkeypatch):
     """sample_KTF draws K, F >= 2 and T >= 1 per step (environments.py:417-427): K != F (no direction fusion), T = 2."""
-    _step_and_compare(tmp_path, gf_dim=8, kf_dim=4, df_dim=8, B=2, K=4, T=2, F=3, H=64, W=96)
+    _step_and_compare(tmp_path, monkeypatch, gf_dim=8, kf_dim=4, df_dim=8, B=2, K=4, T=2, F=3, H=64, W=96)
 
 
 @pytest.mark.gpu

@@ -27,6 +27,7 @@ def main(args=None):
     opt = TrainOptions().parse(args, allow_unknown=True)
     if getattr(opt, 'miopen_find_mode', None):          # before the first convolution reaches MIOpen
         os.environ['MIOPEN_FIND_MODE'] = opt.miopen_find_mode
+    vfi.configure_miopen()                              # FAST find mode unless set; one find-db / kernel cache per rank
     rank, world, local_rank = parallel.init_from_env()
     if getattr(opt, 'winograd_arithmetic', 'fp32') != 'fp32':
         from video_frame_inpainting_amd import conv_ops
