@@ -237,8 +237,10 @@ int tai_conv3x3_wino43_forward(const float* x, const float* U, const float* bias
  *                        is not produced. */
 int tai_conv3x3_wino43_forward_ex(const float* const* xs, int nparts, const float* U, const float* bias, float* y, float* ypool,
                                   const float* addx, float* y2, int N, int C, int K, int H, int W, int act, void* hip_stream);
-/* Waves per workgroup of that kernel, process-wide: 8 (default: two per SIMD, 16 channels x 16 tiles each) or 4 (one per SIMD, 32 x 16
- * each; A/B); the same bits.
+/* Form of that kernel, process-wide: 0 (default since round 5): eight waves with the whole channel-chunk loop as one generated asm
+ * statement (csrc/wino43_chunkloop.inc, tools/gen_wino43_asm.py); 8 / 4: round 4's compiler-scheduled forms with eight waves (two per
+ * SIMD, 16 channels x 16 tiles each) or four (one per SIMD, 32 x 16 each), kept for A/B: the same bits as each other; the generated
+ * form shares the +- pairs of B^T in the patch transform, so it differs from them by rounding.
  * Returns the previous value, -1 on a bad one. */
 int tai_conv3x3_wino43_set_waves(int waves);
 /* ... with the input given as 1 to 4 equal channel parts (contiguous [N, C / nparts, H, W] tensors; C / nparts a multiple of 4): the

@@ -1,0 +1,399 @@
+#!/usr/bin/env python3
+"""Generates video-frame-inpainting_amd/csrc/wino43_chunkloop.inc: the whole channel-chunk loop of the Winograd F(4x4, 3x3)
+kernel (csrc/wino43_conv.hip.inc, conv3x3_gen) as ONE inline-asm block with a fixed register map.
+
+Why generated: the HIP C++ form of the eight-wave kernel (round 4) asked for 144 accumulator registers per wave under a
+256-register budget and got 128 AGPRs: the compiler moved 16 accumulators between the two register files around their MFMAs
+on every chunk (~48 v_accvgpr_read/write per wave and chunk, four of them directly behind the MFMA they wait for), kept the
+wave's role (patch half 0 / half 1 / weight copy) in branches and v_cndmask selects inside the loop, spent a vector add per
+LDS operand address, and its asm patch loads relied on the compiler never touching their destination registers before a
+wait it could not see.  Here every register, load, wait and MFMA has a fixed place:
+
+  roles (wave-uniform, three separate code paths): waves 0-1 patch half A (columns 0-2 of B^T d B), waves 2-3 patch half B
+  (columns 3-5), waves 4-7 weight DMA; every wave owns 16 output channels x 16 tiles x 36 positions = 144 accumulators a[0:143].
+
+  per chunk of 4 input channels (LDS double-buffered, stage = chunk & 1, one s_barrier per chunk), wave program:
+    all    : ds_read_b128 of position group 0's operands;
+    patch  : s_waitcnt vmcnt(0) (the patch rows loaded during the previous chunk), transform chunk + 1 (row pass 6 x 6,
+             column pass 3 x 12 = 72 vector instructions, the +-pairs of B^T shared), 6 LDS writes into the other stage,
+             then the 12 buffer loads of chunk + 2;
+    copy   : the nine 1 KB LDS-DMAs of chunk + 1's transformed weights into the other stage;
+    all    : 9 groups of 4 v_mfma_f32_16x16x4_f32, operands of group g + 1 read while group g runs, LDS offsets as immediates;
+    all    : s_waitcnt (DMA landed / LDS writes done), s_barrier, stage toggle.
+
+Register map -- VGPR:
+    v[0:3] v[4:7]     A operand (transformed weights), two buffers        v[8:11] v[12:15]  B operand (transformed patches)
+    v[16+4r : 19+4r]  patch row r, columns 1..4 (r = 0..5)                 v[40+r]           patch row r, column 0 (half A) / 5 (half B)
+    v[46:61]          INPUT  off_mid[6], off_edge[6], A read base, B read base, LDS write base, 16 * lane
+    v62 v63 v64       current A / B read address, current write address (stage toggled by v_sub from the sums below)
+    v65 v66 v67       (stage 0 + stage 1) sums of the three
+    v[68:85]          row-pass results R[r][c] (6 rows x 3 columns)         v[86:91]  temporaries
+    column-pass results reuse v[16:33] (the patch rows are dead by then)
+SGPR:
+    s[48:63]  INPUT  part bases (4 x lo, hi), part bytes, chunks per part, chunks, bytes per chunk, weight pointer (lo, hi), role, -
+    s[64:67]  buffer descriptor of the current part      s68 soffset       s69 chunks left in the part
+    s70 remaining chunks   s[72:73] weight DMA pointer   s74 / s75 DMA LDS destination of the other / this stage   s76 scratch
+    s[78:83]  bases of the parts still to come
+Outputs: a[0:143] (position p, channel register q  ->  a[4 p + q]).
+"""
+import os
+
+KC, TM, TN = 4, 64, 32
+U_STAGE_B = 9 * KC * TM * 4 * 4          # 36,864
+V_STAGE_B = 9 * KC * TN * 4 * 4          # 18,432
+STAGE_B = U_STAGE_B + V_STAGE_B          # 55,296
+
+A_BUF = (0, 4)
+B_BUF = (8, 12)
+D_MID = lambda r: 16 + 4 * r             # x1..x4 of patch row r
+D_EDGE = lambda r: 40 + r
+V_IN = 46                                # v[46:61]
+OFF_MID = lambda r: V_IN + r
+OFF_EDGE = lambda r: V_IN + 6 + r
+IN_ABASE, IN_BBASE, IN_WBASE, IN_LANE16 = V_IN + 12, V_IN + 13, V_IN + 14, V_IN + 15
+V_RA, V_RB, V_W = 62, 63, 64
+V_SA, V_SB, V_SW = 65, 66, 67
+ROWP = lambda r, c: 68 + 3 * r + c       # c = 0..2 within the half
+TMP = 86
+V_LAST = 91
+
+S_IN = 48
+S_PART = lambda i: (S_IN + 2 * i, S_IN + 2 * i + 1)
+S_PART_BYTES, S_CPP, S_NCHUNKS, S_STEP, S_ULO, S_UHI, S_ROLE = S_IN + 8, S_IN + 9, S_IN + 10, S_IN + 11, S_IN + 12, S_IN + 13, S_IN + 14
+S_DESC = 64
+S_SOFF, S_LEFT, S_REM = 68, 69, 70
+S_WP = 72
+S_DST_OTHER, S_DST_THIS, S_T = 74, 75, 76
+S_NEXT = 78                               # s[78:83]: bases of parts 1..3, rotated down at every part switch (even: s_mov_b64)
+
+NEG5 = '0xc0a00000'
+
+
+def position(i, j):
+    return ((i >> 1) * 6 + j) * 2 + (i & 1)
+
+
+class Emitter(object):
+    def __init__(self):
+        self.lines = []
+
+    def __call__(self, fmt, *a):
+        self.lines.append(fmt % a if a else fmt)
+
+    def label(self, name):
+        self.lines.append('%s_%%=:' % name)
+
+    def ref(self, name):
+        return '%s_%%=' % name
+
+
+def quad(r):
+    return 'v[%d:%d]' % (r, r + 3)
+
+
+def emit_read(e, g, buf):
+    """operands of position group g into buffer pair `buf`"""
+    e('ds_read_b128 %s, v%d offset:%d', quad(A_BUF[buf]), V_RA, g * KC * TM * 16)
+    e('ds_read_b128 %s, v%d offset:%d', quad(B_BUF[buf]), V_RB, g * KC * TN * 16)
+
+
+def emit_mfma_phase(e, extra=None, pending_lds=0):
+    """36 MFMAs on the current stage.  Group 0's operands were requested at the top of the chunk (buffer 0); `extra(g)` emits what the
+    role interleaves behind group g's operand request (nothing that touches lgkmcnt)."""
+    for g in range(9):
+        buf = g & 1
+        if g < 8:
+            emit_read(e, g + 1, buf ^ 1)
+        if extra:
+            extra(g)
+        e('s_waitcnt lgkmcnt(%d)', 2 if g < 8 else 0)
+        for j in range(4):
+            p = 4 * g + j
+            e('v_mfma_f32_16x16x4_f32 a[%d:%d], v%d, v%d, a[%d:%d]', 4 * p, 4 * p + 3, A_BUF[buf] + j, B_BUF[buf] + j, 4 * p, 4 * p + 3)
+
+
+def emit_patch_loads(e, tag):
+    """the 12 loads of the next patch rows (current part / soffset), then the part state advances by one chunk"""
+    for r in range(6):
+        e('buffer_load_dwordx4 %s, v%d, s[%d:%d], s%d offen', quad(D_MID(r)), OFF_MID(r), S_DESC, S_DESC + 3, S_SOFF)
+        e('buffer_load_dword v%d, v%d, s[%d:%d], s%d offen', D_EDGE(r), OFF_EDGE(r), S_DESC, S_DESC + 3, S_SOFF)
+    # advance: soffset += bytes per chunk; at the end of a part: next part's base, soffset 0
+    e('s_add_u32 s%d, s%d, s%d', S_SOFF, S_SOFF, S_STEP)
+    e('s_sub_u32 s%d, s%d, 1', S_LEFT, S_LEFT)
+    e('s_cmp_lg_u32 s%d, 0', S_LEFT)
+    e('s_cbranch_scc1 %s', e.ref('SAMEPART_' + tag))
+    e('s_mov_b32 s%d, s%d', S_DESC, S_NEXT)
+    e('s_and_b32 s%d, s%d, 0xffff', S_DESC + 1, S_NEXT + 1)
+    e('s_mov_b64 s[%d:%d], s[%d:%d]', S_NEXT, S_NEXT + 1, S_NEXT + 2, S_NEXT + 3)
+    e('s_mov_b64 s[%d:%d], s[%d:%d]', S_NEXT + 2, S_NEXT + 3, S_NEXT + 4, S_NEXT + 5)
+    e('s_mov_b32 s%d, 0', S_SOFF)
+    e('s_mov_b32 s%d, s%d', S_LEFT, S_CPP)
+    e.label('SAMEPART_' + tag)
+
+
+def bt_rows_half(e, half, x, out, t0, t1):
+    """the three B^T rows of a half applied to six values.  half 0: x = [x0, x1, x2, x3, x4] -> rows 0, 1, 2;
+    half 1: x = [x1, x2, x3, x4, x5] -> rows 3, 4, 5.  out: three destination registers.  6 instructions."""
+    if half == 0:
+        x0, x1, x2, x3, x4 = x
+        e('v_fmamk_f32 v%d, v%d, %s, v%d', out[0], x2, NEG5, x4)          # x4 - 5 x2
+        e('v_fma_f32 v%d, -4.0, v%d, v%d', t0, x2, x4)                     # p = x4 - 4 x2
+        e('v_fma_f32 v%d, -4.0, v%d, v%d', t1, x1, x3)                     # q = x3 - 4 x1
+        e('v_fmac_f32 v%d, 4.0, v%d', out[0], x0)                          # row 0 = 4 x0 - 5 x2 + x4
+        e('v_add_f32 v%d, v%d, v%d', out[1], t0, t1)                       # row 1 = p + q
+        e('v_sub_f32 v%d, v%d, v%d', out[2], t0, t1)                       # row 2 = p - q
+    else:
+        x1, x2, x3, x4, x5 = x
+        e('v_fmamk_f32 v%d, v%d, %s, v%d', out[2], x3, NEG5, x5)          # x5 - 5 x3
+        e('v_sub_f32 v%d, v%d, v%d', t0, x4, x2)                           # p = x4 - x2
+        e('v_sub_f32 v%d, v%d, v%d', t1, x3, x1)                           # s = x3 - x1
+        e('v_fmac_f32 v%d, 4.0, v%d', out[2], x1)                          # row 5 = 4 x1 - 5 x3 + x5
+        e('v_fma_f32 v%d, 2.0, v%d, v%d', out[0], t1, t0)                  # row 3 = p + 2 s
+        e('v_fma_f32 v%d, -2.0, v%d, v%d', out[1], t1, t0)                 # row 4 = p - 2 s
+
+
+def bt_rows_all(e, x, out, t):
+    """all six B^T rows applied to x[0..5] -> out[0..5]; 12 instructions; t: four temporaries."""
+    x0, x1, x2, x3, x4, x5 = x
+    e('v_fmamk_f32 v%d, v%d, %s, v%d', out[0], x2, NEG5, x4)
+    e('v_fmamk_f32 v%d, v%d, %s, v%d', out[5], x3, NEG5, x5)
+    e('v_fma_f32 v%d, -4.0, v%d, v%d', t[0], x2, x4)
+    e('v_fma_f32 v%d, -4.0, v%d, v%d', t[1], x1, x3)
+    e('v_sub_f32 v%d, v%d, v%d', t[2], x4, x2)
+    e('v_sub_f32 v%d, v%d, v%d', t[3], x3, x1)
+    e('v_fmac_f32 v%d, 4.0, v%d', out[0], x0)
+    e('v_fmac_f32 v%d, 4.0, v%d', out[5], x1)
+    e('v_add_f32 v%d, v%d, v%d', out[1], t[0], t[1])
+    e('v_sub_f32 v%d, v%d, v%d', out[2], t[0], t[1])
+    e('v_fma_f32 v%d, 2.0, v%d, v%d', out[3], t[3], t[2])
+    e('v_fma_f32 v%d, -2.0, v%d, v%d', out[4], t[3], t[2])
+
+
+def emit_transform(e, half):
+    """B^T d B of this thread's three columns from the patch registers, written to the stage at v64 (V_W).
+    R[r][c] = B^T row (3 half + c) applied to row r of d (row pass), V[i][c] = B^T row i applied to column c of R (column pass)."""
+    for r in range(6):
+        m = D_MID(r)
+        x = [D_EDGE(r), m, m + 1, m + 2, m + 3] if half == 0 else [m, m + 1, m + 2, m + 3, D_EDGE(r)]
+        bt_rows_half(e, half, x, [ROWP(r, 0), ROWP(r, 1), ROWP(r, 2)], TMP, TMP + 1)
+    # column pass; results into v[16:33]: per row pair ip a quad (the half's two columns that share a position group) and a pair
+    if half == 0:
+        quad_cols, pair_col = (0, 1), 2
+    else:
+        quad_cols, pair_col = (1, 2), 0          # columns 4, 5 share a group; column 3 is the odd one
+    QUAD = lambda ip: 16 + 4 * ip                # v[16:27]
+    PAIR = lambda ip: 28 + 2 * ip                # v[28:33]
+    for c in range(3):
+        out = []
+        for i in range(6):
+            ip, e2 = i >> 1, i & 1
+            if c == pair_col:
+                out.append(PAIR(ip) + e2)
+            else:
+                out.append(QUAD(ip) + 2 * quad_cols.index(c) + e2)
+        bt_rows_all(e, [ROWP(r, c) for r in range(6)], out, [TMP, TMP + 1, TMP + 2, TMP + 3])
+    for ip in range(3):
+        cq, cp = 3 * half + quad_cols[0], 3 * half + pair_col
+        pq, pp = position(2 * ip, cq), position(2 * ip, cp)
+        assert pq % 4 == 0 and pp % 2 == 0 and position(2 * ip + 1, cq) == pq + 1 and position(2 * ip, cq + 1) == pq + 2
+        e('ds_write_b128 v%d, %s offset:%d', V_W, quad(QUAD(ip)), (pq >> 2) * KC * TN * 16)
+        e('ds_write_b64 v%d, v[%d:%d] offset:%d', V_W, PAIR(ip), PAIR(ip) + 1, (pp >> 2) * KC * TN * 16 + (pp & 3) * 4)
+
+
+def emit_dma(e):
+    """nine 1 KB runs of the next chunk's transformed weights: global -> LDS (M0 = destination, + 16 * lane)"""
+    e('s_mov_b32 m0, s%d', S_DST_OTHER)
+    for r in range(9):
+        e('s_nop 0')
+        e('global_load_lds_dwordx4 v%d, s[%d:%d]', IN_LANE16, S_WP, S_WP + 1)
+        e('s_add_u32 s%d, s%d, 0x1000', S_WP, S_WP)
+        e('s_addc_u32 s%d, s%d, 0', S_WP + 1, S_WP + 1)
+        if r < 8:
+            e('s_add_u32 m0, m0, 0x1000')
+
+
+def emit_toggle(e, patch):
+    e('v_sub_u32 v%d, v%d, v%d', V_RA, V_SA, V_RA)
+    e('v_sub_u32 v%d, v%d, v%d', V_RB, V_SB, V_RB)
+    if patch:
+        e('v_sub_u32 v%d, v%d, v%d', V_W, V_SW, V_W)
+    else:
+        e('s_mov_b32 s%d, s%d', S_T, S_DST_OTHER)
+        e('s_mov_b32 s%d, s%d', S_DST_OTHER, S_DST_THIS)
+        e('s_mov_b32 s%d, s%d', S_DST_THIS, S_T)
+
+
+def emit_role(e, role):
+    """role 0 / 1: patch half A / B; role 2: weight copy"""
+    tag = 'R%d' % role
+    patch = role < 2
+    e.label('ROLE_' + tag)
+    if patch:
+        e('s_setprio 2')
+        # ---- prologue: patch rows of chunk 0, transformed into stage 0; the rows of chunk 1 requested
+        emit_patch_loads(e, tag + 'P0')
+        e('s_waitcnt vmcnt(0)')
+        emit_transform(e, role)                          # v64 = write base of stage 0
+        e('s_cmp_lt_u32 s%d, 2', S_REM)
+        e('s_cbranch_scc1 %s', e.ref('PRO_DONE_' + tag))
+        emit_patch_loads(e, tag + 'P1')
+        e.label('PRO_DONE_' + tag)
+        e('v_sub_u32 v%d, v%d, v%d', V_W, V_SW, V_W)   # the loop's transform writes the OTHER stage
+        e('s_waitcnt lgkmcnt(0)')
+    else:
+        emit_dma_first(e)
+        e('s_waitcnt vmcnt(0)')
+    e('s_barrier')
+    # ---- chunk loop
+    e.label('LOOP_' + tag)
+    emit_read(e, 0, 0)
+    if patch:
+        e('s_cmp_lt_u32 s%d, 2', S_REM)                  # a next chunk?
+        e('s_cbranch_scc1 %s', e.ref('NOXF_' + tag))
+        e('s_waitcnt vmcnt(0)')
+        emit_transform(e, role)
+        e('s_cmp_lt_u32 s%d, 3', S_REM)                  # a chunk after that?
+        e('s_cbranch_scc1 %s', e.ref('NOXF_' + tag))
+        emit_patch_loads(e, tag + 'L')
+        e.label('NOXF_' + tag)
+        # (the six LDS writes sit between group 0's and group 1's operand requests: lgkmcnt(2) at group 0 covers them)
+        emit_mfma_phase(e)
+        e('s_waitcnt lgkmcnt(0)')
+    else:
+        e('s_cmp_lt_u32 s%d, 2', S_REM)
+        e('s_cbranch_scc1 %s', e.ref('NODMA_' + tag))
+        emit_dma(e)
+        e.label('NODMA_' + tag)
+        emit_mfma_phase(e)
+        e('s_waitcnt vmcnt(0)')
+    e('s_barrier')
+    emit_toggle(e, patch)
+    e('s_sub_u32 s%d, s%d, 1', S_REM, S_REM)
+    e('s_cmp_lg_u32 s%d, 0', S_REM)
+    e('s_cbranch_scc1 %s', e.ref('LOOP_' + tag))
+    e('s_branch %s', e.ref('END'))
+
+
+def emit_dma_first(e):
+    """chunk 0's weights into stage 0 (destination s75 = this stage), then the pointer stands at chunk 1"""
+    e('s_mov_b32 m0, s%d', S_DST_THIS)
+    for r in range(9):
+        e('s_nop 0')
+        e('global_load_lds_dwordx4 v%d, s[%d:%d]', IN_LANE16, S_WP, S_WP + 1)
+        e('s_add_u32 s%d, s%d, 0x1000', S_WP, S_WP)
+        e('s_addc_u32 s%d, s%d, 0', S_WP + 1, S_WP + 1)
+        if r < 8:
+            e('s_add_u32 m0, m0, 0x1000')
+
+
+def generate():
+    e = Emitter()
+    # ---- common set-up.  (s_nop 4: the scalar inputs may come fresh from v_readfirstlane; they are read by SALU moves first, the
+    # buffer / global instructions only see registers written by the SALU below)
+    e('s_nop 4')
+    for p in range(36):
+        for q in range(4):
+            e('v_accvgpr_write_b32 a%d, 0', 4 * p + q)
+    e('v_mov_b32 v%d, v%d', V_RA, IN_ABASE)
+    e('v_mov_b32 v%d, v%d', V_RB, IN_BBASE)
+    e('v_mov_b32 v%d, v%d', V_W, IN_WBASE)
+    for dst, src in ((V_SA, IN_ABASE), (V_SB, IN_BBASE), (V_SW, IN_WBASE)):      # 2 base + stage bytes (VOP3 takes no literal on gfx9)
+        e('v_lshlrev_b32 v%d, 1, v%d', dst, src)
+        e('v_add_u32 v%d, 0x%x, v%d', dst, STAGE_B, dst)
+    e('s_mov_b32 s%d, s%d', S_DESC, S_PART(0)[0])
+    e('s_and_b32 s%d, s%d, 0xffff', S_DESC + 1, S_PART(0)[1])
+    e('s_mov_b32 s%d, s%d', S_DESC + 2, S_PART_BYTES)
+    e('s_mov_b32 s%d, 0x00020000', S_DESC + 3)
+    for i in range(3):
+        e('s_mov_b64 s[%d:%d], s[%d:%d]', S_NEXT + 2 * i, S_NEXT + 2 * i + 1, S_PART(i + 1)[0], S_PART(i + 1)[1])
+    e('s_mov_b32 s%d, 0', S_SOFF)
+    e('s_mov_b32 s%d, s%d', S_LEFT, S_CPP)
+    e('s_mov_b32 s%d, s%d', S_REM, S_NCHUNKS)
+    e('s_mov_b64 s[%d:%d], s[%d:%d]', S_WP, S_WP + 1, S_ULO, S_UHI)
+    # DMA destinations: (wave & 3) * 1024 inside stage 0 / stage 1; the role word carries it: role | (wave & 3) << 8
+    e('s_lshr_b32 s%d, s%d, 8', S_T, S_ROLE)
+    e('s_lshl_b32 s%d, s%d, 10', S_DST_THIS, S_T)
+    e('s_add_u32 s%d, s%d, %d', S_DST_OTHER, S_DST_THIS, STAGE_B)
+    e('s_and_b32 s%d, s%d, 0xff', S_T, S_ROLE)
+    e('s_cmp_eq_u32 s%d, 0', S_T)
+    e('s_cbranch_scc1 %s', e.ref('ROLE_R0'))
+    e('s_cmp_eq_u32 s%d, 1', S_T)
+    e('s_cbranch_scc1 %s', e.ref('ROLE_R1'))
+    e('s_branch %s', e.ref('ROLE_R2'))
+    for role in (0, 1, 2):
+        emit_role(e, role)
+    e.label('END')
+    e('s_setprio 0')
+    e('s_nop 15')
+    e('s_nop 15')
+    return e.lines
+
+
+def generate_inverse(r):
+    """A^T m A of channel register r: m[i][j] = a[4 position(i, j) + r]  ->  v[0:15] = the 4 x 4 output tile, row-major.
+    Same operation order as store_tiles (csrc/wino43_conv.hip.inc).  Temporaries v[16:49]."""
+    e = Emitter()
+    M = lambda i: 16 + i               # v[16:21] the six values of a column / row
+    S12, D12, S34, D34 = 22, 23, 24, 25
+    T = lambda i, j: 26 + 6 * i + j    # v[26:49]  t[i][j], i = 0..3, j = 0..5
+
+    def at(x, out, with_tail):
+        """x: six registers; out: four registers"""
+        e('v_add_f32 v%d, v%d, v%d', S12, x[1], x[2])
+        e('v_sub_f32 v%d, v%d, v%d', D12, x[1], x[2])
+        e('v_add_f32 v%d, v%d, v%d', S34, x[3], x[4])
+        e('v_sub_f32 v%d, v%d, v%d', D34, x[3], x[4])
+        e('v_add_f32 v%d, v%d, v%d', out[0], x[0], S12)
+        e('v_add_f32 v%d, v%d, v%d', out[0], out[0], S34)                # (m0 + s12) + s34
+        e('v_fma_f32 v%d, 2.0, v%d, v%d', out[1], D34, D12)
+        e('v_fma_f32 v%d, 4.0, v%d, v%d', out[2], S34, S12)
+        e('v_fmamk_f32 v%d, v%d, 0x41000000, v%d', out[3], D34, D12)             # 8 d34 + d12 (8.0 is no inline constant)
+        e('v_add_f32 v%d, v%d, v%d', out[3], out[3], x[5])
+
+    for j in range(6):
+        for i in range(6):
+            e('v_accvgpr_read_b32 v%d, a%d', M(i), 4 * position(i, j) + r)
+        at([M(i) for i in range(6)], [T(i, j) for i in range(4)], True)
+    for i in range(4):
+        at([T(i, j) for j in range(6)], [4 * i + c for c in range(4)], True)
+    return e.lines
+
+
+def inverse_clobbers():
+    return ', '.join(['"v%d"' % i for i in range(16, 50)])
+
+
+def clobbers():
+    v = ['"v%d"' % i for i in list(range(0, V_IN)) + list(range(V_IN + 16, V_LAST + 1))]
+    s = ['"s%d"' % i for i in range(S_DESC, S_NEXT + 6)]
+    return ', '.join(v + s + ['"vcc"', '"scc"', '"memory"'])
+
+
+def main():
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'video-frame-inpainting_amd', 'csrc', 'wino43_chunkloop.inc')
+    lines = generate()
+    n_valu = sum(1 for l in lines if l.startswith('v_') and 'mfma' not in l and 'accvgpr' not in l)
+    text = ['// GENERATED by tools/gen_wino43_asm.py -- do not edit.  Register map and schedule: see the generator.',
+            '// %d instructions (%d MFMAs in three role loops, %d other vector instructions incl. three prologue transforms).'
+            % (sum(1 for l in lines if not l.endswith(':')), sum(1 for l in lines if 'v_mfma' in l), n_valu),
+            '#define TAI_W43_STAGE_BYTES %d' % STAGE_B,
+            '#define TAI_W43_LOOP_ASM \\']
+    for l in lines:
+        text.append('    "%s\\n" \\' % l)
+    text.append('    ""')
+    text.append('#define TAI_W43_LOOP_CLOBBERS %s' % clobbers())
+    for r in range(4):
+        text.append('#define TAI_W43_INVERSE_ASM_R%d \\' % r)
+        for l in generate_inverse(r):
+            text.append('    "%s\\n" \\' % l)
+        text.append('    ""')
+    text.append('#define TAI_W43_INVERSE_CLOBBERS %s' % inverse_clobbers())
+    tmp = out + '.tmp.%d' % os.getpid()
+    with open(tmp, 'w') as f:
+        f.write('\n'.join(text) + '\n')
+    os.replace(tmp, out)
+    print('wrote %s: %d lines' % (os.path.normpath(out), len(lines)))
+
+
+if __name__ == '__main__':
+    main()

@@ -16,6 +16,8 @@ HEADER = os.path.join(_ROOT, 'include', 'tai_sepconv.h')
 CSRC = os.path.join(_PKG, 'csrc')
 MAIN_SOURCE = os.path.join(CSRC, 'sepconv_capi.hip')          # the one translation unit; it #includes every *.inc
 GENERATED = os.path.join(CSRC, 'sepconv_fwd_rowloop.inc')     # written by tools/gen_fwd_asm.py
+GENERATORS = (('gen_fwd_asm.py', GENERATED),                  # (generator under tools/, the include it writes)
+              ('gen_wino43_asm.py', os.path.join(CSRC, 'wino43_chunkloop.inc')))
 
 
 def sources(csrc=None):
@@ -115,11 +117,12 @@ def verify(path, csrc=None, header=None):
 
 
 def regenerate():
-    """Re-run the row-loop generator when it is newer than its output.  The generator writes a temporary file and renames
+    """Re-run the asm generators whose script is newer than its output.  A generator writes a temporary file and renames
     it over the target, so a concurrent hipcc never reads a half-written include."""
-    gen = os.path.join(_ROOT, 'tools', 'gen_fwd_asm.py')
-    if os.path.exists(gen) and (not os.path.exists(GENERATED) or os.path.getmtime(gen) > os.path.getmtime(GENERATED)):
-        subprocess.check_call(['python3', gen], stdout=subprocess.DEVNULL)
+    for name, out in GENERATORS:
+        gen = os.path.join(_ROOT, 'tools', name)
+        if os.path.exists(gen) and (not os.path.exists(out) or os.path.getmtime(gen) > os.path.getmtime(out)):
+            subprocess.check_call(['python3', gen], stdout=subprocess.DEVNULL)
 
 
 def lib():

@@ -678,9 +678,11 @@ int tai_conv3x3_wino43_transform_weights(const float* weight, float* U, int K, i
     return check_launch("wino43_transform_weights");
 }
 
-static std::atomic<int> g_wino43_waves{8};        // waves per workgroup of the F(4x4, 3x3) kernel: 8 (two per SIMD, default: 3-6 % faster) or 4
+// form of the F(4x4, 3x3) kernel: 0 (default) the generated chunk loop (eight waves, csrc/wino43_chunkloop.inc); 8 / 4: round 4's
+// compiler-scheduled forms with eight / four waves per workgroup (A/B)
+static std::atomic<int> g_wino43_waves{0};
 int tai_conv3x3_wino43_set_waves(int waves) {
-    if (waves != 4 && waves != 8) return -1;
+    if (waves != 0 && waves != 4 && waves != 8) return -1;
     return g_wino43_waves.exchange(waves, std::memory_order_relaxed);
 }
 
@@ -711,7 +713,22 @@ static int wino43_forward_impl(const float* const* xs, int nparts, const float* 
         hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(W8 ? 512 : 256), wino43::LDS_BYTES, s, p[0], p[1], p[2], p[3], \
                            cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, ypool, addx, y2);                          \
     }
-    if (ypool) {                                   // second outputs: the eight-wave form only
+#define TAI_W43_LAUNCH_GEN(A, E)                                                                                                \
+    {                                                                                                                           \
+        auto kern = wino43::conv3x3_gen<A, E>;                                                                                  \
+        if (int rc = allow_lds(kern, wino43::LDS_BYTES)) return rc;                                                             \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(512), wino43::LDS_BYTES, s, p[0], p[1], p[2], p[3],   \
+                           cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, ypool, addx, y2);                          \
+    }
+    if (g_wino43_waves.load(std::memory_order_relaxed) == 0) {      // the generated chunk loop (default)
+        if (ypool) {
+            if (act == 0) TAI_W43_LAUNCH_GEN(0, 1) else TAI_W43_LAUNCH_GEN(1, 1)
+        } else if (addx) {
+            if (y2) TAI_W43_LAUNCH_GEN(0, 2) else TAI_W43_LAUNCH_GEN(0, 3)
+        } else {
+            if (act == 0) TAI_W43_LAUNCH_GEN(0, 0) else if (act == 1) TAI_W43_LAUNCH_GEN(1, 0) else TAI_W43_LAUNCH_GEN(2, 0)
+        }
+    } else if (ypool) {                            // second outputs: the eight-wave form only
         if (act == 0) TAI_W43_LAUNCH(0, true, 1) else TAI_W43_LAUNCH(1, true, 1)
     } else if (addx) {
         if (y2) TAI_W43_LAUNCH(0, true, 2) else TAI_W43_LAUNCH(0, true, 3)
@@ -721,6 +738,7 @@ static int wino43_forward_impl(const float* const* xs, int nparts, const float* 
         if (act == 0) TAI_W43_LAUNCH(0, false, 0) else if (act == 1) TAI_W43_LAUNCH(1, false, 0) else TAI_W43_LAUNCH(2, false, 0)
     }
 #undef TAI_W43_LAUNCH
+#undef TAI_W43_LAUNCH_GEN
     return check_launch("conv3x3_wino43");
 }
 
