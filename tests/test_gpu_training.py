@@ -27,7 +27,8 @@ GRAD_KEYS = ('generator.motion_enc.dyn_conv1.0.weight',      # first convolution
              'kernelnet.moduleVertical1.7.weight', 'kernelnet.moduleHorizontal2.7.bias')
 LOSS_RTOL = 2e-4          # loss terms, relative
 GRAD_RTOL = 5e-3          # generator: max |g_gpu - g_oracle| <= GRAD_RTOL * max |g_oracle| per parameter
-D_GRAD_RTOL = 5e-3        # discriminator (measured: <= 3.3e-3, profiles/r02_training_parity.txt)
+D_GRAD_RTOL = 2e-5        # discriminator, the oracle differentiating on the product's side of every LeakyReLU kink (_KinkSides): measured <= 6.6e-7
+                          # (profiles/r05_training_parity.txt; with the oracle's own sides 3.3e-3 -- one element, tests/test_train_oracle_cpu.py)
 
 
 @pytest.fixture(autouse=True)
@@ -180,10 +181,17 @@ def test_training_step_full_width_at_the_32_clip_dispatch(tmp_path, monkeypatch,
     from conftest import miopen_convolutions
     _, prof = _step_and_compare(tmp_path, monkeypatch, gf_dim=64, kf_dim=32, df_dim=64, B=2, profile=True, tag='32-clip dispatch')
     convs = miopen_convolutions(prof)
-    outside = [c for c in convs if tuple(c[1][2 if 'backward' in c[0] else 1][-2:]) != (4, 4)]
-    assert convs and not outside, outside[:8]
+    weight_of = lambda c: tuple(c[1][2 if 'backward' in c[0] else 1])
+    outside = [c for c in convs if weight_of(c)[-2:] != (4, 4)]
+    # what is left outside the discriminator: the WEIGHT gradients of the kernel network's 8 x 8 and 4 x 4 layers -- tai_conv3x3_wino_wrw
+    # takes rows of 16 pixels (conv_ops.wino_weight_grad: W % 16 == 0), so these go to aten.convolution_backward at every batch size,
+    # 32 clips included: the route configs[2] takes, compared with the oracle here as everything else
+    small = [c for c in outside if c[0] == 'aten::convolution_backward' and c[1][0][-1] < 16 and weight_of(c)[-2:] == (3, 3)]
+    shapes = sorted(set((c[0], tuple(c[1][0]), weight_of(c)) for c in outside))
+    print('ATen convolutions: %d in the discriminator (4 x 4 stride 2), %d outside it: %s' % (len(convs) - len(outside), len(outside), shapes))
+    assert convs and len(small) == len(outside), [c for c in outside if c not in small][:8]
     r = dispatch_at_32_clips.routes
-    print('routes taken: %s; ATen convolutions (all 4 x 4, the discriminator): %d' % (r, len(convs)))
+    print('routes taken: %s' % r)
     assert r['wino'] > 100
 
 

@@ -43,8 +43,8 @@ U_STAGE_B = 9 * KC * TM * 4 * 4          # 36,864
 V_STAGE_B = 9 * KC * TN * 4 * 4          # 18,432
 STAGE_B = U_STAGE_B + V_STAGE_B          # 55,296
 
-A_BUF = (0, 4)
-B_BUF = (8, 12)
+A_BUF = (0, 4, 92)                        # three buffers: operands are requested two position groups ahead
+B_BUF = (8, 12, 96)
 D_MID = lambda r: 16 + 4 * r             # x1..x4 of patch row r
 D_EDGE = lambda r: 40 + r
 V_IN = 46                                # v[46:61]
@@ -55,7 +55,7 @@ V_RA, V_RB, V_W = 62, 63, 64
 V_SA, V_SB, V_SW = 65, 66, 67
 ROWP = lambda r, c: 68 + 3 * r + c       # c = 0..2 within the half
 TMP = 86
-V_LAST = 91
+V_LAST = 99
 
 S_IN = 48
 S_PART = lambda i: (S_IN + 2 * i, S_IN + 2 * i + 1)
@@ -67,6 +67,7 @@ S_DST_OTHER, S_DST_THIS, S_T = 74, 75, 76
 S_NEXT = 78                               # s[78:83]: bases of parts 1..3, rotated down at every part switch (even: s_mov_b64)
 
 NEG5 = '0xc0a00000'
+ABLATE = set()         # timing experiments of the tools build only (results are then wrong): see ABLATIONS below
 
 
 def position(i, j):
@@ -93,31 +94,38 @@ def quad(r):
 
 def emit_read(e, g, buf):
     """operands of position group g into buffer pair `buf`"""
+    if 'noreads' in ABLATE:
+        return
     e('ds_read_b128 %s, v%d offset:%d', quad(A_BUF[buf]), V_RA, g * KC * TM * 16)
     e('ds_read_b128 %s, v%d offset:%d', quad(B_BUF[buf]), V_RB, g * KC * TN * 16)
 
 
-def emit_mfma_phase(e, extra=None, pending_lds=0):
-    """36 MFMAs on the current stage.  Group 0's operands were requested at the top of the chunk (buffer 0); `extra(g)` emits what the
-    role interleaves behind group g's operand request (nothing that touches lgkmcnt)."""
+def emit_mfma_phase(e, extra=None):
+    """36 MFMAs on the current stage.  The operands of groups 0 and 1 were requested just before (buffers 0, 1; nothing else on lgkmcnt
+    behind them); group g + 2 is requested while group g runs.  `extra(g)` emits what the role interleaves in front of group g's MFMAs
+    (vector-memory instructions of the next chunk: issued all at once behind the barrier they queue at the CU's one address unit and
+    block the wave's MFMAs behind them)."""
     for g in range(9):
-        buf = g & 1
-        if g < 8:
-            emit_read(e, g + 1, buf ^ 1)
+        if g < 7:
+            emit_read(e, g + 2, (g + 2) % 3)
         if extra:
             extra(g)
-        e('s_waitcnt lgkmcnt(%d)', 2 if g < 8 else 0)
-        for j in range(4):
+        e('s_waitcnt lgkmcnt(%d)', 4 if g < 7 else (2 if g == 7 else 0))
+        buf = g % 3
+        for j in range(0 if 'nomfma' in ABLATE else 4):
             p = 4 * g + j
             e('v_mfma_f32_16x16x4_f32 a[%d:%d], v%d, v%d, a[%d:%d]', 4 * p, 4 * p + 3, A_BUF[buf] + j, B_BUF[buf] + j, 4 * p, 4 * p + 3)
 
 
-def emit_patch_loads(e, tag):
-    """the 12 loads of the next patch rows (current part / soffset), then the part state advances by one chunk"""
-    for r in range(6):
-        e('buffer_load_dwordx4 %s, v%d, s[%d:%d], s%d offen', quad(D_MID(r)), OFF_MID(r), S_DESC, S_DESC + 3, S_SOFF)
-        e('buffer_load_dword v%d, v%d, s[%d:%d], s%d offen', D_EDGE(r), OFF_EDGE(r), S_DESC, S_DESC + 3, S_SOFF)
-    # advance: soffset += bytes per chunk; at the end of a part: next part's base, soffset 0
+def emit_patch_row_load(e, r):
+    if 'noloads' in ABLATE:
+        return
+    e('buffer_load_dwordx4 %s, v%d, s[%d:%d], s%d offen', quad(D_MID(r)), OFF_MID(r), S_DESC, S_DESC + 3, S_SOFF)
+    e('buffer_load_dword v%d, v%d, s[%d:%d], s%d offen', D_EDGE(r), OFF_EDGE(r), S_DESC, S_DESC + 3, S_SOFF)
+
+
+def emit_patch_advance(e, tag):
+    """the part state advances by one chunk: soffset += bytes per chunk; at the end of a part: next part's base, soffset 0"""
     e('s_add_u32 s%d, s%d, s%d', S_SOFF, S_SOFF, S_STEP)
     e('s_sub_u32 s%d, s%d, 1', S_LEFT, S_LEFT)
     e('s_cmp_lg_u32 s%d, 0', S_LEFT)
@@ -129,6 +137,13 @@ def emit_patch_loads(e, tag):
     e('s_mov_b32 s%d, 0', S_SOFF)
     e('s_mov_b32 s%d, s%d', S_LEFT, S_CPP)
     e.label('SAMEPART_' + tag)
+
+
+def emit_patch_loads(e, tag):
+    """the 12 loads of the next patch rows (current part / soffset), then the state advances"""
+    for r in range(6):
+        emit_patch_row_load(e, r)
+    emit_patch_advance(e, tag)
 
 
 def bt_rows_half(e, half, x, out, t0, t1):
@@ -172,7 +187,7 @@ def bt_rows_all(e, x, out, t):
 def emit_transform(e, half):
     """B^T d B of this thread's three columns from the patch registers, written to the stage at v64 (V_W).
     R[r][c] = B^T row (3 half + c) applied to row r of d (row pass), V[i][c] = B^T row i applied to column c of R (column pass)."""
-    for r in range(6):
+    for r in range(0 if 'noxform' in ABLATE else 6):
         m = D_MID(r)
         x = [D_EDGE(r), m, m + 1, m + 2, m + 3] if half == 0 else [m, m + 1, m + 2, m + 3, D_EDGE(r)]
         bt_rows_half(e, half, x, [ROWP(r, 0), ROWP(r, 1), ROWP(r, 2)], TMP, TMP + 1)
@@ -183,7 +198,7 @@ def emit_transform(e, half):
         quad_cols, pair_col = (1, 2), 0          # columns 4, 5 share a group; column 3 is the odd one
     QUAD = lambda ip: 16 + 4 * ip                # v[16:27]
     PAIR = lambda ip: 28 + 2 * ip                # v[28:33]
-    for c in range(3):
+    for c in range(0 if 'noxform' in ABLATE else 3):
         out = []
         for i in range(6):
             ip, e2 = i >> 1, i & 1
@@ -200,16 +215,18 @@ def emit_transform(e, half):
         e('ds_write_b64 v%d, v[%d:%d] offset:%d', V_W, PAIR(ip), PAIR(ip) + 1, (pp >> 2) * KC * TN * 16 + (pp & 3) * 4)
 
 
-def emit_dma(e):
-    """nine 1 KB runs of the next chunk's transformed weights: global -> LDS (M0 = destination, + 16 * lane)"""
-    e('s_mov_b32 m0, s%d', S_DST_OTHER)
-    for r in range(9):
-        e('s_nop 0')
-        e('global_load_lds_dwordx4 v%d, s[%d:%d]', IN_LANE16, S_WP, S_WP + 1)
-        e('s_add_u32 s%d, s%d, 0x1000', S_WP, S_WP)
-        e('s_addc_u32 s%d, s%d, 0', S_WP + 1, S_WP + 1)
-        if r < 8:
-            e('s_add_u32 m0, m0, 0x1000')
+def emit_dma_piece(e, r):
+    """run r of the nine 1 KB runs of the next chunk's transformed weights: global -> LDS (M0 = destination, + 16 * lane)"""
+    if 'nodma' in ABLATE:
+        return
+    if r == 0:
+        e('s_mov_b32 m0, s%d', S_DST_OTHER)
+    else:
+        e('s_add_u32 m0, m0, 0x1000')
+    e('s_nop 0')
+    e('global_load_lds_dwordx4 v%d, s[%d:%d]', IN_LANE16, S_WP, S_WP + 1)
+    e('s_add_u32 s%d, s%d, 0x1000', S_WP, S_WP)
+    e('s_addc_u32 s%d, s%d, 0', S_WP + 1, S_WP + 1)
 
 
 def emit_toggle(e, patch):
@@ -244,29 +261,43 @@ def emit_role(e, role):
         emit_dma_first(e)
         e('s_waitcnt vmcnt(0)')
     e('s_barrier')
-    # ---- chunk loop
+    # ---- chunk loop.  Two bodies per role: with a next chunk (its loads / DMA interleaved with the MFMA groups) and the last chunk.
     e.label('LOOP_' + tag)
-    emit_read(e, 0, 0)
     if patch:
         e('s_cmp_lt_u32 s%d, 2', S_REM)                  # a next chunk?
-        e('s_cbranch_scc1 %s', e.ref('NOXF_' + tag))
-        e('s_waitcnt vmcnt(0)')
-        emit_transform(e, role)
+        e('s_cbranch_scc1 %s', e.ref('PLAIN_' + tag))
+        e('s_waitcnt vmcnt(0)')                           # its patch rows (requested during the previous chunk)
+        emit_transform(e, role)                           # ... transformed into the other stage
+        emit_read(e, 0, 0)
+        emit_read(e, 1, 1)
         e('s_cmp_lt_u32 s%d, 3', S_REM)                  # a chunk after that?
-        e('s_cbranch_scc1 %s', e.ref('NOXF_' + tag))
-        emit_patch_loads(e, tag + 'L')
-        e.label('NOXF_' + tag)
-        # (the six LDS writes sit between group 0's and group 1's operand requests: lgkmcnt(2) at group 0 covers them)
+        e('s_cbranch_scc1 %s', e.ref('PLAIN_NOREAD_' + tag))
+        # its 12 loads, one patch row in front of each of the first six MFMA groups
+        emit_mfma_phase(e, lambda g: emit_patch_row_load(e, g) if g < 6 else None)
+        emit_patch_advance(e, tag + 'L')
+        e('s_branch %s', e.ref('CHUNK_END_' + tag))
+        e.label('PLAIN_' + tag)
+        emit_read(e, 0, 0)
+        emit_read(e, 1, 1)
+        e.label('PLAIN_NOREAD_' + tag)
         emit_mfma_phase(e)
+        e.label('CHUNK_END_' + tag)
         e('s_waitcnt lgkmcnt(0)')
     else:
+        emit_read(e, 0, 0)
+        emit_read(e, 1, 1)
         e('s_cmp_lt_u32 s%d, 2', S_REM)
-        e('s_cbranch_scc1 %s', e.ref('NODMA_' + tag))
-        emit_dma(e)
-        e.label('NODMA_' + tag)
+        e('s_cbranch_scc1 %s', e.ref('PLAIN_' + tag))
+        # the nine DMAs of the next chunk's weights in front of the first six groups (2, 1, 2, 1, 2, 1): the last one has three groups to land in
+        pieces = {0: (0, 1), 1: (2,), 2: (3, 4), 3: (5,), 4: (6, 7), 5: (8,)}
+        emit_mfma_phase(e, lambda g: [emit_dma_piece(e, r) for r in pieces.get(g, ())])
+        e('s_branch %s', e.ref('CHUNK_END_' + tag))
+        e.label('PLAIN_' + tag)
         emit_mfma_phase(e)
+        e.label('CHUNK_END_' + tag)
         e('s_waitcnt vmcnt(0)')
-    e('s_barrier')
+    if 'nobarrier' not in ABLATE:
+        e('s_barrier')
     emit_toggle(e, patch)
     e('s_sub_u32 s%d, s%d, 1', S_REM, S_REM)
     e('s_cmp_lg_u32 s%d, 0', S_REM)
@@ -284,6 +315,11 @@ def emit_dma_first(e):
         e('s_addc_u32 s%d, s%d, 0', S_WP + 1, S_WP + 1)
         if r < 8:
             e('s_add_u32 m0, m0, 0x1000')
+
+
+ABLATIONS = {1: {'noxform'}, 2: {'noloads'}, 3: {'nodma'}, 4: {'nobarrier'}, 5: {'nomfma'}, 6: {'noxform', 'noloads', 'nodma'},
+             7: {'noxform', 'noloads', 'nodma', 'nobarrier'}, 8: {'noxform', 'noloads', 'nodma', 'nobarrier', 'noreads'},
+             9: {'noxform', 'noloads'}}
 
 
 def generate():
@@ -382,6 +418,17 @@ def main():
         text.append('    "%s\\n" \\' % l)
     text.append('    ""')
     text.append('#define TAI_W43_LOOP_CLOBBERS %s' % clobbers())
+    text.append('#ifdef TAI_TIMING_VARIANTS   // timing experiments (wrong results by design): tools build only')
+    for v, flags in sorted(ABLATIONS.items()):
+        ABLATE.clear()
+        ABLATE.update(flags)
+        text.append('// V%d: %s' % (v, ' '.join(sorted(flags))))
+        text.append('#define TAI_W43_LOOP_ASM_V%d \\' % v)
+        for l in generate():
+            text.append('    "%s\\n" \\' % l)
+        text.append('    ""')
+    ABLATE.clear()
+    text.append('#endif')
     for r in range(4):
         text.append('#define TAI_W43_INVERSE_ASM_R%d \\' % r)
         for l in generate_inverse(r):

@@ -682,6 +682,9 @@ int tai_conv3x3_wino43_transform_weights(const float* weight, float* U, int K, i
 // compiler-scheduled forms with eight / four waves per workgroup (A/B)
 static std::atomic<int> g_wino43_waves{0};
 int tai_conv3x3_wino43_set_waves(int waves) {
+#ifdef TAI_TIMING_VARIANTS   // 101..109: ablations of the generated loop (timing only, wrong results; tools/gen_wino43_asm.py ABLATIONS)
+    if (waves >= 101 && waves <= 109) return g_wino43_waves.exchange(waves, std::memory_order_relaxed);
+#endif
     if (waves != 0 && waves != 4 && waves != 8) return -1;
     return g_wino43_waves.exchange(waves, std::memory_order_relaxed);
 }
@@ -720,6 +723,23 @@ static int wino43_forward_impl(const float* const* xs, int nparts, const float* 
         hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(512), wino43::LDS_BYTES, s, p[0], p[1], p[2], p[3],   \
                            cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, ypool, addx, y2);                          \
     }
+#ifdef TAI_TIMING_VARIANTS
+#define TAI_W43_LAUNCH_VAR(V)                                                                                                   \
+    {                                                                                                                           \
+        auto kern = wino43::conv3x3_gen<1, 0, V>;                                                                               \
+        if (int rc = allow_lds(kern, wino43::LDS_BYTES)) return rc;                                                             \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(512), wino43::LDS_BYTES, s, p[0], p[1], p[2], p[3],   \
+                           cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, ypool, addx, y2);                          \
+        return check_launch("conv3x3_wino43 (ablation)");                                                                       \
+    }
+    switch (g_wino43_waves.load(std::memory_order_relaxed)) {
+        case 101: TAI_W43_LAUNCH_VAR(1) case 102: TAI_W43_LAUNCH_VAR(2) case 103: TAI_W43_LAUNCH_VAR(3) case 104: TAI_W43_LAUNCH_VAR(4)
+        case 105: TAI_W43_LAUNCH_VAR(5) case 106: TAI_W43_LAUNCH_VAR(6) case 107: TAI_W43_LAUNCH_VAR(7) case 108: TAI_W43_LAUNCH_VAR(8)
+        case 109: TAI_W43_LAUNCH_VAR(9)
+        default: break;
+    }
+#undef TAI_W43_LAUNCH_VAR
+#endif
     if (g_wino43_waves.load(std::memory_order_relaxed) == 0) {      // the generated chunk loop (default)
         if (ypool) {
             if (act == 0) TAI_W43_LAUNCH_GEN(0, 1) else TAI_W43_LAUNCH_GEN(1, 1)
