@@ -225,7 +225,8 @@ int tai_conv3x3_wino_forward_ex(const float* const* xs, int nparts, int shift_k,
  * instead of 16 per 2 x 2 -- 1.78x fewer MFMAs, ~7x the fp32 rounding error per layer; meant for the layers with C >= 128 and
  * K >= 128, where the bi-TAI forward's end-to-end error is unchanged (profiles/r04_wino_f43_study.txt, r04_wino43_default_parity.txt):
  * the Python side (conv_ops) sends exactly those layers here by default.  Own transformed-weight
- * layout (tai_conv3x3_wino43_weight_floats / _transform_weights); H, W and C multiples of 4; act as above.  Replaces the same
+ * layout (tai_conv3x3_wino43_weight_floats / _transform_weights); H and W multiples of 4; C any (the transformed weights are zero-padded
+ * to a multiple of 4 channels); act as above.  Replaces the same
  * reference layers as tai_conv3x3_wino_forward (src/models/mcnet/mcnet.py:79-118,131-152,165-176,198-224). */
 long long tai_conv3x3_wino43_weight_floats(int K, int C);
 int tai_conv3x3_wino43_transform_weights(const float* weight, float* U, int K, int C, void* hip_stream);
@@ -237,6 +238,18 @@ int tai_conv3x3_wino43_forward(const float* x, const float* U, const float* bias
  *                        is not produced. */
 int tai_conv3x3_wino43_forward_ex(const float* const* xs, int nparts, const float* U, const float* bias, float* y, float* ypool,
                                   const float* addx, float* y2, int N, int C, int K, int H, int W, int act, void* hip_stream);
+/* The k x k "same" convolutions of MotionEnc (nn.Conv2d(gf, 2gf, 5, padding=2), nn.Conv2d(2gf, 4gf, 7, padding=3):
+ * src/models/mcnet/mcnet.py:36-38, 45-47) on the same kernel: tai_conv3x3_wino_forward_ex's displaced-read form (shift_k = k, S = (k + 2) / 3,
+ * x ONE plane [N, C / S^2, in_h, in_w] that carries its halo and is read S x S times, channel block (a, b) displaced by (3a, 3b) pixels;
+ * U from the k x k filter cut into S x S blocks of 3 x 3 taps, zero past k: [K, S^2 * Cin, 3, 3] through
+ * tai_conv3x3_wino43_transform_weights) with the 4 x 4 tile: 1.78x fewer MFMAs than there.  The pixel under output (0, 0)'s centre tap of
+ * block (0, 0) is at (in_oy, in_ox) (any in_ox >= 1: the patch rows are loaded 4-byte aligned); the plane must cover rows
+ * in_oy - 1 ... in_oy + H + 3 (S - 1) and columns in_ox - 1 ... in_ox + W + 3 (S - 1), halo zero.  ypool (may be NULL): 2x2 max pool of
+ * the activated output, into a plane of pool_h x pool_w with its origin at (pool_oy, pool_ox) (pool_w, pool_ox even; pool_h = 0: a plain
+ * [N, K, H/2, W/2] tensor).  act 0 / 1; C / S^2, H, W multiples of 4. */
+int tai_conv3x3_wino43_forward_blocks(const float* x, int shift_k, const float* U, const float* bias, float* y, float* ypool, int pool_h,
+                                      int pool_w, int pool_oy, int pool_ox, int N, int C, int K, int H, int W, int in_h, int in_w, int in_oy,
+                                      int in_ox, int act, void* hip_stream);
 /* Form of that kernel, process-wide: 0 (default since round 5): eight waves with the whole channel-chunk loop as one generated asm
  * statement (csrc/wino43_chunkloop.inc, tools/gen_wino43_asm.py); 8 / 4: round 4's compiler-scheduled forms with eight waves (two per
  * SIMD, 16 channels x 16 tiles each) or four (one per SIMD, 32 x 16 each), kept for A/B: the same bits as each other; the generated

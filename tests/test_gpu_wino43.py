@@ -43,8 +43,9 @@ def _operands(N, C, K, H, W, seed=0):
 
 
 # (N, C, K, H, W): one tile, tiles that straddle images and workgroups, K that is not a multiple of 64, C = 4, bi-TAI shapes
+# ... and channel counts that are not multiples of 4 (the kernel network's 51 -> 51 and 65 -> 64 layers: zero-padded weights)
 SHAPES = [(1, 4, 64, 4, 4), (2, 8, 70, 12, 12), (3, 128, 128, 8, 20), (5, 12, 3, 4, 8), (2, 256, 256, 32, 32), (8, 512, 130, 16, 16),
-          (4, 128, 256, 64, 64)]
+          (4, 128, 256, 64, 64), (3, 51, 51, 16, 24), (2, 65, 64, 8, 12), (2, 1, 5, 4, 4)]
 
 
 @pytest.mark.parametrize('act', [None, 'relu', 'tanh'])
@@ -152,9 +153,13 @@ def test_wino43_rejects_what_it_cannot_run():
     y = torch.empty(1, 64, 8, 8, device='cuda')
     U = torch.empty(L.tai_conv3x3_wino43_weight_floats(64, 8), device='cuda')
     s = torch.cuda.current_stream().cuda_stream
-    assert L.tai_conv3x3_wino43_weight_floats(64, 6) == 0                                                     # C % 4
+    assert L.tai_conv3x3_wino43_weight_floats(64, 6) == 36 * 64 * 8                                           # C padded to a multiple of 4
     assert L.tai_conv3x3_wino43_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 8, 64, 6, 8, 0, s) != 0      # H % 4
-    assert L.tai_conv3x3_wino43_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 6, 64, 8, 8, 0, s) != 0      # C % 4
+    prev = L.tai_conv3x3_wino43_set_waves(8)            # C % 4: the generated form only
+    assert L.tai_conv3x3_wino43_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 6, 64, 8, 8, 0, s) != 0
+    L.tai_conv3x3_wino43_set_waves(prev)
+    xs2 = (ctypes.c_void_p * 2)(x.data_ptr(), x.data_ptr())
+    assert L.tai_conv3x3_wino43_forward_parts(xs2, 2, U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 12, 64, 8, 8, 0, s) != 0     # parts of 6 channels
     assert L.tai_conv3x3_wino43_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 8, 64, 8, 8, 3, s) != 0      # act
     assert L.tai_conv3x3_wino43_forward(None, U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 8, 64, 8, 8, 0, s) != 0
 
@@ -189,7 +194,7 @@ def test_conv_ops_takes_the_4x4_tile_only_when_asked_and_only_on_wide_layers(mon
     from video_frame_inpainting_amd import conv_ops
     monkeypatch.setattr(conv_ops, 'WINO43_MIN_WORKGROUPS', 1)
     x, w, b = _operands(16, 128, 128, 32, 32)          # (conv_ops leaves layers of fewer than 72 F(2x2, 3x3) workgroups to MIOpen)
-    xs, ws, bs = _operands(16, 64, 64, 32, 32)
+    xs, ws, bs = _operands(32, 64, 64, 32, 32)
     with torch.no_grad():
         before = conv_ops.set_winograd_tile(2)
         y2, y2s = conv_ops.conv_bias_act(x, w, b, 1, 'relu'), conv_ops.conv_bias_act(xs, ws, bs, 1, 'relu')
@@ -198,9 +203,17 @@ def test_conv_ops_takes_the_4x4_tile_only_when_asked_and_only_on_wide_layers(mon
             assert before == 4 and prev == 2 and conv_ops.get_winograd_tile() == 4
             y4, y4s = conv_ops.conv_bias_act(x, w, b, 1, 'relu'), conv_ops.conv_bias_act(xs, ws, bs, 1, 'relu')
             y4p = conv_ops.conv_bias_act((x[:, :64].contiguous(), x[:, 64:].contiguous()), w, b, 1, 'relu')
+            # a narrow layer outside MC-Net's recurrence (the kernel network, the merge residuals: conv_ops.mark_outside_recurrence)
+            narrow = torch.nn.Conv2d(64, 64, 3, padding=1).cuda()
+            with torch.no_grad():
+                narrow.weight.copy_(ws)
+                narrow.bias.copy_(bs)
+            conv_ops.mark_outside_recurrence(narrow)
+            y4m = conv_ops.conv_bias_act(xs, narrow.weight, narrow.bias, 1, 'relu')
         finally:
             conv_ops.set_winograd_tile(before)
-    assert torch.equal(y4s, y2s)                                  # C = K = 64: stays on F(2x2, 3x3)
+    assert torch.equal(y4s, y2s)                                  # C = K = 64: stays on F(2x2, 3x3) ...
+    assert not torch.equal(y4m, y2s) and torch.equal(y4m, _run([xs], ws, bs, 'relu'))       # ... unless the layer is marked
     assert not torch.equal(y4, y2) and torch.equal(y4, _run([x], w, b, 'relu')) and torch.equal(y4p, y4)
     assert float((y4 - y2).abs().max()) <= 1e-4 * float(y2.abs().max())
     with pytest.raises(ValueError):
@@ -239,3 +252,72 @@ def test_full_width_forward_with_the_4x4_tile_matches_cpu_oracle(monkeypatch):
     p4, s4, _ = metrics.compute_errors(o4['pred'].cpu().numpy(), GT.numpy())
     pr, sr, _ = metrics.compute_errors(ref['pred'].numpy(), GT.numpy())
     assert np.abs(np.asarray(p4) - np.asarray(pr)).max() <= 0.01 and np.abs(np.asarray(s4) - np.asarray(sr)).max() <= 1e-4
+
+
+@pytest.mark.parametrize('k,N,Cin,K,H,W', [(5, 3, 8, 70, 8, 12), (7, 2, 16, 64, 16, 16), (5, 5, 64, 128, 64, 64), (7, 3, 128, 256, 32, 32)])
+def test_wino43_displaced_read_blocks_match_fp64_kxk_conv(k, N, Cin, K, H, W):
+    """MotionEnc's 5 x 5 / 7 x 7 "same" convolutions (mcnet.py:36-47) on the 4 x 4 tile: the halo-carrying plane read S x S times
+    (tai_conv3x3_wino43_forward_blocks) against an fp64 k x k convolution; the pooled output plain and into the window of a larger
+    plane whose halo must stay untouched."""
+    from video_frame_inpainting_amd import _native, conv_ops
+    L = _native.lib()
+    g = torch.Generator().manual_seed(k + N + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(K, Cin, k, k, generator=g) * (2.0 / (k * k * Cin)) ** 0.5).cuda()
+    b = torch.randn(K, generator=g).cuda()
+    S, top, left, in_h, in_w = conv_ops.halo_geometry(H, W, k)
+    plane = torch.zeros(N, Cin, in_h, in_w, device='cuda')
+    plane[:, :, top:top + H, left:left + W] = x
+    wb = conv_ops._block3x3_weight(w)
+    s = torch.cuda.current_stream().cuda_stream
+    U = torch.empty(L.tai_conv3x3_wino43_weight_floats(K, S * S * Cin), device='cuda')
+    _native.check(L.tai_conv3x3_wino43_transform_weights(wb.data_ptr(), U.data_ptr(), K, S * S * Cin, s), 'transform')
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=k // 2))
+    mag = F.conv2d(x.double().abs(), w.double().abs(), b.double().abs(), padding=k // 2)
+    y = torch.full((N, K, H, W), float('nan'), device='cuda')
+    yp = torch.full((N, K, H // 2, W // 2), float('nan'), device='cuda')
+    _native.check(L.tai_conv3x3_wino43_forward_blocks(plane.data_ptr(), k, U.data_ptr(), b.data_ptr(), y.data_ptr(), yp.data_ptr(), 0, 0, 0, 0,
+                                                      N, S * S * Cin, K, H, W, in_h, in_w, 1, 2, 1, s), 'blocks')
+    assert torch.isfinite(y).all()
+    assert float(((y.double() - ref).abs() / (1 + mag)).max()) <= TOL
+    assert torch.equal(yp, F.max_pool2d(y, 2))
+    # ... the pooled output into the window (3, 4) of a plane with a sentinel halo, no plain output requested twice
+    ph, pw = H // 2 + 7, W // 2 + 10
+    big = torch.full((N, K, ph, pw), 7.0, device='cuda')
+    y2 = torch.empty_like(y)
+    _native.check(L.tai_conv3x3_wino43_forward_blocks(plane.data_ptr(), k, U.data_ptr(), b.data_ptr(), y2.data_ptr(), big.data_ptr(), ph, pw, 3, 4,
+                                                      N, S * S * Cin, K, H, W, in_h, in_w, 1, 2, 1, s), 'blocks window')
+    assert torch.equal(y2, y) and torch.equal(big[:, :, 3:3 + H // 2, 4:4 + W // 2], yp)
+    big[:, :, 3:3 + H // 2, 4:4 + W // 2] = 7.0
+    assert bool((big == 7.0).all())
+    # refusals: a plane without the halo, an odd window
+    assert L.tai_conv3x3_wino43_forward_blocks(plane.data_ptr(), k, U.data_ptr(), b.data_ptr(), y.data_ptr(), None, 0, 0, 0, 0,
+                                               N, S * S * Cin, K, H, W, in_h - 1, in_w, 1, 2, 1, s) != 0
+    assert L.tai_conv3x3_wino43_forward_blocks(plane.data_ptr(), k, U.data_ptr(), b.data_ptr(), y.data_ptr(), big.data_ptr(), ph, pw, 3, 3,
+                                               N, S * S * Cin, K, H, W, in_h, in_w, 1, 2, 1, s) != 0
+
+
+def test_motion_enc_chain_on_the_4x4_tile_matches_the_2x2_tile(monkeypatch):
+    """conv_ops.motion_enc_chain (MotionEnc's three stages, each pooled output written into the next stage's halo plane) with the 5x5 / 7x7
+    stages on tai_conv3x3_wino43_forward_blocks against the same chain on F(2x2, 3x3)."""
+    from video_frame_inpainting_amd import conv_ops
+    monkeypatch.setattr(conv_ops, 'WINO43_MIN_WORKGROUPS', 1)
+    monkeypatch.setattr(conv_ops, 'WINO_MIN_WORKGROUPS', 1)
+    torch.manual_seed(4)
+    c1, c2, c3 = (torch.nn.Conv2d(1, 16, 5, padding=2).cuda(), torch.nn.Conv2d(16, 32, 5, padding=2).cuda(),
+                  torch.nn.Conv2d(32, 64, 7, padding=3).cuda())
+    diff = torch.randn(6, 1, 64, 64, device='cuda')
+    outs = {}
+    with torch.no_grad():
+        for tile in (2, 4):
+            prev = conv_ops.set_winograd_tile(tile)
+            try:
+                p3, res = conv_ops.motion_enc_chain(diff, c1, c2, c3)
+                outs[tile] = [p3.clone()] + [r.clone() for r in res]
+            finally:
+                conv_ops.set_winograd_tile(prev)
+        want = F.max_pool2d(torch.relu(c3(F.max_pool2d(torch.relu(c2(F.max_pool2d(torch.relu(c1(diff)), 2))), 2))), 2)
+    assert not torch.equal(outs[4][0], outs[2][0])
+    for a, b in zip(outs[4], outs[2]):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+    assert float((outs[4][0] - want).abs().max()) <= 1e-4 * float(want.abs().max())

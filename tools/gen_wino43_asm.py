@@ -67,6 +67,7 @@ S_DST_OTHER, S_DST_THIS, S_T = 74, 75, 76
 S_NEXT = 78                               # s[78:83]: bases of parts 1..3, rotated down at every part switch (even: s_mov_b64)
 
 NEG5 = '0xc0a00000'
+BLOCKS = [False]       # generate the displaced-read form (k x k filters as S x S blocks of 3 x 3 taps: see emit_patch_advance)
 ABLATE = set()         # timing experiments of the tools build only (results are then wrong): see ABLATIONS below
 
 
@@ -125,16 +126,29 @@ def emit_patch_row_load(e, r):
 
 
 def emit_patch_advance(e, tag):
-    """the part state advances by one chunk: soffset += bytes per chunk; at the end of a part: next part's base, soffset 0"""
+    """the input state advances by one chunk: soffset += bytes per chunk.  At the end of a part (parts form): the next part's base,
+    soffset 0.  Displaced-read form (BLOCKS: ONE tensor, a plane that carries its halo, read S x S times -- channel block (a, b)
+    displaced by (3a, 3b) pixels, the k x k filters of MotionEnc cut into 3 x 3 blocks): at the end of a block the soffset restarts at
+    the next block's displacement, 12 bytes further along the row, or -- s80 counting the blocks left in the row -- one block row down."""
     e('s_add_u32 s%d, s%d, s%d', S_SOFF, S_SOFF, S_STEP)
     e('s_sub_u32 s%d, s%d, 1', S_LEFT, S_LEFT)
     e('s_cmp_lg_u32 s%d, 0', S_LEFT)
     e('s_cbranch_scc1 %s', e.ref('SAMEPART_' + tag))
-    e('s_mov_b32 s%d, s%d', S_DESC, S_NEXT)
-    e('s_and_b32 s%d, s%d, 0xffff', S_DESC + 1, S_NEXT + 1)
-    e('s_mov_b64 s[%d:%d], s[%d:%d]', S_NEXT, S_NEXT + 1, S_NEXT + 2, S_NEXT + 3)
-    e('s_mov_b64 s[%d:%d], s[%d:%d]', S_NEXT + 2, S_NEXT + 3, S_NEXT + 4, S_NEXT + 5)
-    e('s_mov_b32 s%d, 0', S_SOFF)
+    if BLOCKS[0]:
+        # s78 = displacement of the current block (bytes), s80 = blocks left in this block row; inputs: s50 = bytes from the last block of a
+        # row to the first of the next (3 in_w - 3 (S - 1)) * 4, s52 = S
+        e('s_sub_u32 s%d, s%d, 1', S_NEXT + 2, S_NEXT + 2)
+        e('s_cmp_lg_u32 s%d, 0', S_NEXT + 2)
+        e('s_cselect_b32 s%d, 12, s%d', S_T, S_PART(1)[0])
+        e('s_cselect_b32 s%d, s%d, s%d', S_NEXT + 2, S_NEXT + 2, S_PART(2)[0])        # (before the add: it rewrites SCC)
+        e('s_add_u32 s%d, s%d, s%d', S_NEXT, S_NEXT, S_T)
+        e('s_mov_b32 s%d, s%d', S_SOFF, S_NEXT)
+    else:
+        e('s_mov_b32 s%d, s%d', S_DESC, S_NEXT)
+        e('s_and_b32 s%d, s%d, 0xffff', S_DESC + 1, S_NEXT + 1)
+        e('s_mov_b64 s[%d:%d], s[%d:%d]', S_NEXT, S_NEXT + 1, S_NEXT + 2, S_NEXT + 3)
+        e('s_mov_b64 s[%d:%d], s[%d:%d]', S_NEXT + 2, S_NEXT + 3, S_NEXT + 4, S_NEXT + 5)
+        e('s_mov_b32 s%d, 0', S_SOFF)
     e('s_mov_b32 s%d, s%d', S_LEFT, S_CPP)
     e.label('SAMEPART_' + tag)
 
@@ -340,8 +354,12 @@ def generate():
     e('s_and_b32 s%d, s%d, 0xffff', S_DESC + 1, S_PART(0)[1])
     e('s_mov_b32 s%d, s%d', S_DESC + 2, S_PART_BYTES)
     e('s_mov_b32 s%d, 0x00020000', S_DESC + 3)
-    for i in range(3):
-        e('s_mov_b64 s[%d:%d], s[%d:%d]', S_NEXT + 2 * i, S_NEXT + 2 * i + 1, S_PART(i + 1)[0], S_PART(i + 1)[1])
+    if BLOCKS[0]:
+        e('s_mov_b32 s%d, 0', S_NEXT)                            # displacement of block (0, 0)
+        e('s_mov_b32 s%d, s%d', S_NEXT + 2, S_PART(2)[0])       # blocks left in the block row: S
+    else:
+        for i in range(3):
+            e('s_mov_b64 s[%d:%d], s[%d:%d]', S_NEXT + 2 * i, S_NEXT + 2 * i + 1, S_PART(i + 1)[0], S_PART(i + 1)[1])
     e('s_mov_b32 s%d, 0', S_SOFF)
     e('s_mov_b32 s%d, s%d', S_LEFT, S_CPP)
     e('s_mov_b32 s%d, s%d', S_REM, S_NCHUNKS)
@@ -418,6 +436,13 @@ def main():
         text.append('    "%s\\n" \\' % l)
     text.append('    ""')
     text.append('#define TAI_W43_LOOP_CLOBBERS %s' % clobbers())
+    BLOCKS[0] = True
+    text.append('// the displaced-read form: one halo-carrying plane read S x S times (k x k filters as blocks of 3 x 3 taps)')
+    text.append('#define TAI_W43_LOOP_ASM_BLOCKS \\')
+    for l in generate():
+        text.append('    "%s\\n" \\' % l)
+    text.append('    ""')
+    BLOCKS[0] = False
     text.append('#ifdef TAI_TIMING_VARIANTS   // timing experiments (wrong results by design): tools build only')
     for v, flags in sorted(ABLATIONS.items()):
         ABLATE.clear()

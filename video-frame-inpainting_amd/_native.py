@@ -166,6 +166,8 @@ def lib():
     L.tai_conv3x3_wino43_forward_parts.restype = I
     L.tai_conv3x3_wino43_forward_ex.argtypes = [P, I, P, P, P, P, P, P, I, I, I, I, I, I, V]
     L.tai_conv3x3_wino43_forward_ex.restype = I
+    L.tai_conv3x3_wino43_forward_blocks.argtypes = [P, I, P, P, P, P] + [I] * 14 + [V]
+    L.tai_conv3x3_wino43_forward_blocks.restype = I
     L.tai_conv3x3_wino43_set_waves.argtypes = [I]
     L.tai_conv3x3_wino43_set_waves.restype = I
     L.tai_conv3x3_wino_forward.restype = I

@@ -89,9 +89,21 @@ def get_winograd_tile():
     return _WINO_TILE[0]
 
 
-def _wino43_ok(N, Ci, Co, H, W, nparts=1):
-    return (_WINO_TILE[0] == 4 and Ci >= WINO43_MIN_CHANNELS and Co >= WINO43_MIN_CHANNELS and H % 4 == 0 and W % 4 == 0
-            and Ci % nparts == 0 and (Ci // nparts) % 4 == 0 and N * max(Ci, Co) * H * W < 2 ** 29
+def mark_outside_recurrence(module):
+    """Tell the dispatch that ``module``'s 3x3 layers may take F(4x4, 3x3) whatever their width.  F(4x4, 3x3)'s rounding is ~7x
+    F(2x2, 3x3)'s per layer; inside MC-Net's recurrence (every prediction is the next step's input) that only stays invisible on the
+    layers with C, K >= 128, but the kernel network and the merge residuals feed the separable convolution once per output frame:
+    with all of them on the 4 x 4 tile the forward's end-to-end error against float64 is that of the round-4 default (pred 2.4e-6 against
+    2.4e-6 at T = 5, 8.2e-6 against 6.6e-6 at T = 10, pred_forward / pred_backward untouched: profiles/r05_wino_f43_policy_study.txt).
+    TAIFillInModel marks kernelnet and merge_residual{1,2,3} (tai.py)."""
+    for p in module.parameters():
+        p._tai_f43_any_width = True
+
+
+def _wino43_ok(N, Ci, Co, H, W, nparts=1, weight=None):
+    wide = (Ci >= WINO43_MIN_CHANNELS and Co >= WINO43_MIN_CHANNELS) or (Ci >= 16 and getattr(weight, '_tai_f43_any_width', False))
+    return (_WINO_TILE[0] == 4 and wide and H % 4 == 0 and W % 4 == 0
+            and Ci % nparts == 0 and ((Ci // nparts) % 4 == 0 or nparts == 1) and N * max(Ci, Co) * H * W < 2 ** 29
             and ((N * (H // 4) * (W // 4) + 31) // 32) * ((Co + 63) // 64) >= WINO43_MIN_WORKGROUPS)
 
 
@@ -162,6 +174,28 @@ def _wino_weights_kxk(weight, transposed=False):
                           'tai_conv3x3_wino_transform_weights')
         return U
     return _cached(weight, ('wino_kxk', transposed), make)
+
+
+def _wino43_weights_kxk(weight):
+    """The k x k filter as S x S blocks of 3 x 3 taps in the F(4x4, 3x3) layout (tai_conv3x3_wino43_forward_blocks)."""
+    def make():
+        w = _block3x3_weight(weight.detach())
+        K, C = w.shape[0], w.shape[1]
+        L = _native.lib()
+        U = torch.empty(L.tai_conv3x3_wino43_weight_floats(K, C), dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            _native.check(L.tai_conv3x3_wino43_transform_weights(w.data_ptr(), U.data_ptr(), K, C,
+                                                                 torch.cuda.current_stream(w.device).cuda_stream),
+                          'tai_conv3x3_wino43_transform_weights')
+        return U
+    return _cached(weight, ('wino43_kxk',), make)
+
+
+def _wino43_blocks_ok(N, Cin, Co, H, W):
+    """MotionEnc's 5x5 / 7x7 layers on the 4 x 4 tile (displaced reads): the 7x7 (128 -> 256) is a wide layer, the 5x5 (64 -> 128) was
+    measured parity-neutral too (profiles/r05_wino_f43_policy_study.txt: "big + MotionEnc 5x5")."""
+    return (_WINO_TILE[0] == 4 and Cin % 4 == 0 and Cin >= 16 and H % 4 == 0 and W % 4 == 0
+            and ((N * (H // 4) * (W // 4) + 31) // 32) * ((Co + 63) // 64) >= WINO43_MIN_WORKGROUPS)
 
 
 def _kxk_as_wino(x, weight, bias, act, pool, transposed=False, keep_stack=False):
@@ -259,19 +293,30 @@ def motion_enc_chain(diff, conv1, conv2, conv3):
     p3 = torch.empty((N, 4 * g, H4 // 2, W4 // 2), dtype=torch.float32, device=dev)
     plane2 = halo_plane(N, g, H2, W2, 5, dev)
     plane3 = halo_plane(N, 2 * g, H4, W4, 7, dev)
-    U2, U3 = _wino_weights_kxk(ws[1]), _wino_weights_kxk(ws[2])
+    U2 = None if _wino43_blocks_ok(N, g, 2 * g, H2, W2) else _wino_weights_kxk(ws[1])
+    U3 = None if _wino43_blocks_ok(N, 2 * g, 4 * g, H4, W4) else _wino_weights_kxk(ws[2])
     xs2 = (ctypes.c_void_p * 1)(plane2.data_ptr())
     xs3 = (ctypes.c_void_p * 1)(plane3.data_ptr())
     with torch.cuda.device(dev):
         _native.check(L.tai_conv_cin1_forward_maxpool_window(diff.data_ptr(), ws[0].contiguous().data_ptr(), bs[0].data_ptr(),
                                                             c1.data_ptr(), plane2.data_ptr(), N, g, H, W, 5, 1, ih2, iw2, top2, left2,
                                                             stream), 'tai_conv_cin1_forward_maxpool_window')
-        _native.check(L.tai_conv3x3_wino_forward_ex(xs2, 1, 5, U2.data_ptr(), bs[1].data_ptr(), c2.data_ptr(), plane3.data_ptr(),
-                                                   ih3, iw3, top3, left3, None, None, N, S2 * S2 * g, 2 * g, H2, W2, ih2, iw2, 1, 2, 1,
-                                                   stream), 'tai_conv3x3_wino_forward_ex')
-        _native.check(L.tai_conv3x3_wino_forward_ex(xs3, 1, 7, U3.data_ptr(), bs[2].data_ptr(), c3.data_ptr(), p3.data_ptr(),
-                                                   0, 0, 0, 0, None, None, N, S3 * S3 * 2 * g, 4 * g, H4, W4, ih3, iw3, 1, 2, 1,
-                                                   stream), 'tai_conv3x3_wino_forward_ex')
+        if _wino43_blocks_ok(N, g, 2 * g, H2, W2):               # the 4 x 4 tile (set_winograd_tile): 1.78x fewer MFMAs
+            _native.check(L.tai_conv3x3_wino43_forward_blocks(plane2.data_ptr(), 5, _wino43_weights_kxk(ws[1]).data_ptr(), bs[1].data_ptr(),
+                                                             c2.data_ptr(), plane3.data_ptr(), ih3, iw3, top3, left3, N, S2 * S2 * g, 2 * g,
+                                                             H2, W2, ih2, iw2, 1, 2, 1, stream), 'tai_conv3x3_wino43_forward_blocks')
+        else:
+            _native.check(L.tai_conv3x3_wino_forward_ex(xs2, 1, 5, U2.data_ptr(), bs[1].data_ptr(), c2.data_ptr(), plane3.data_ptr(),
+                                                       ih3, iw3, top3, left3, None, None, N, S2 * S2 * g, 2 * g, H2, W2, ih2, iw2, 1, 2, 1,
+                                                       stream), 'tai_conv3x3_wino_forward_ex')
+        if _wino43_blocks_ok(N, 2 * g, 4 * g, H4, W4):
+            _native.check(L.tai_conv3x3_wino43_forward_blocks(plane3.data_ptr(), 7, _wino43_weights_kxk(ws[2]).data_ptr(), bs[2].data_ptr(),
+                                                             c3.data_ptr(), p3.data_ptr(), 0, 0, 0, 0, N, S3 * S3 * 2 * g, 4 * g,
+                                                             H4, W4, ih3, iw3, 1, 2, 1, stream), 'tai_conv3x3_wino43_forward_blocks')
+        else:
+            _native.check(L.tai_conv3x3_wino_forward_ex(xs3, 1, 7, U3.data_ptr(), bs[2].data_ptr(), c3.data_ptr(), p3.data_ptr(),
+                                                       0, 0, 0, 0, None, None, N, S3 * S3 * 2 * g, 4 * g, H4, W4, ih3, iw3, 1, 2, 1,
+                                                       stream), 'tai_conv3x3_wino_forward_ex')
     return p3, [c1, c2, c3]
 
 
@@ -299,7 +344,7 @@ def conv_bias_unpool_add(x, weight, bias, padding, addx, keep_plain=True):
     y = torch.empty((N, Co, H, W), dtype=torch.float32, device=x0.device)
     y2 = torch.empty_like(y) if keep_plain else None
     ptrs = (ctypes.c_void_p * len(parts))(*[q.data_ptr() for q in parts])
-    if _wino43_ok(N, Ci, Co, H, W, len(parts)):              # wide layer: F(4x4, 3x3) (set_winograd_tile): a tile holds four unpooling cells
+    if _wino43_ok(N, Ci, Co, H, W, len(parts), weight):      # wide layer: F(4x4, 3x3) (set_winograd_tile): a tile holds four unpooling cells
         U = _wino43_weights(weight, False)
         with torch.cuda.device(x0.device):
             _native.check(L.tai_conv3x3_wino43_forward_ex(ptrs, len(parts), U.data_ptr(), bias.data_ptr(), y.data_ptr(), None, addx.data_ptr(),
@@ -760,7 +805,7 @@ def conv_bias_act_maxpool(x, weight, bias, padding, act):
                     _native.check(L.tai_conv_cin1_forward_maxpool(x.data_ptr(), weight.contiguous().data_ptr(), bias.data_ptr(),
                                                                   y.data_ptr(), yp.data_ptr(), N, Co, H, W, kh, _ACT[act], stream),
                                   'tai_conv_cin1_forward_maxpool')
-                elif kh == kw == 3 and padding == 1 and _wino43_ok(N, Ci, Co, H, W):      # wide layer: F(4x4, 3x3): a tile is four pooling windows
+                elif kh == kw == 3 and padding == 1 and _wino43_ok(N, Ci, Co, H, W, 1, weight):      # wide layer: F(4x4, 3x3): a tile is four pooling windows
                     U = _wino43_weights(weight, False)
                     xs = (ctypes.c_void_p * 1)(x.data_ptr())
                     _native.check(L.tai_conv3x3_wino43_forward_ex(xs, 1, U.data_ptr(), bias.data_ptr(), y.data_ptr(), yp.data_ptr(), None, None,
@@ -817,7 +862,7 @@ def _conv_bias_act(x, weight, bias, padding, act, transposed, out):
         y = out if _usable_out(out, (N, Co, H, W), x0) else torch.empty((N, Co, H, W), dtype=x0.dtype, device=x0.device)
         ptrs = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
         with torch.cuda.device(x0.device):
-            if _wino43_ok(N, Ci, Co, H, W, len(parts)):      # wide layer: F(4x4, 3x3) (set_winograd_tile)
+            if _wino43_ok(N, Ci, Co, H, W, len(parts), weight):      # wide layer: F(4x4, 3x3) (set_winograd_tile)
                 U = _wino43_weights(weight, transposed)
                 _native.check(L.tai_conv3x3_wino43_forward_parts(ptrs, len(parts), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci,
                                                                  Co, H, W, _ACT[act], torch.cuda.current_stream(x0.device).cuda_stream),
@@ -878,7 +923,7 @@ def _conv_bias_act(x, weight, bias, padding, act, transposed, out):
         x = x.contiguous()
         y = out if _usable_out(out, (N, Co, H, W), x) else torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device)
         with torch.cuda.device(x.device):
-            if _wino43_ok(N, Ci, Co, H, W):                  # wide layer: F(4x4, 3x3) (set_winograd_tile)
+            if _wino43_ok(N, Ci, Co, H, W, 1, weight):       # wide layer: F(4x4, 3x3) (set_winograd_tile)
                 U = _wino43_weights(weight, transposed)
                 _native.check(L.tai_conv3x3_wino43_forward(x.data_ptr(), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci, Co,
                                                            H, W, _ACT[act], stream), 'tai_conv3x3_wino43_forward')

@@ -661,20 +661,22 @@ int tai_conv3x3_wino_transform_weights(const float* weight, float* U, int K, int
 
 // ---- Winograd F(4x4, 3x3) on the fp32 MFMA pipe (csrc/wino43_conv.hip.inc): opt-in prototype -------------------------------------
 long long tai_conv3x3_wino43_weight_floats(int K, int C) {
-    if (K <= 0 || C <= 0 || C % wino43::KC != 0) return 0;
+    if (K <= 0 || C <= 0) return 0;
     const long long Kpad = (K + wino43::TM - 1) / wino43::TM * wino43::TM;
-    return 36 * Kpad * C;
+    const long long Cpad = (C + wino43::KC - 1) / wino43::KC * wino43::KC;       // zero weights for the channels past C
+    return 36 * Kpad * Cpad;
 }
 
 int tai_conv3x3_wino43_transform_weights(const float* weight, float* U, int K, int C, void* hip_stream) {
     g_err[0] = 0;
-    if (!weight || !U || K <= 0 || C <= 0 || C % wino43::KC != 0)
-        return fail(TAI_SEPCONV_EINVAL, "%s", "wino43 transform_weights: bad argument (C must be a multiple of 4)");
+    if (!weight || !U || K <= 0 || C <= 0)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "wino43 transform_weights: bad argument");
     const int Kpad = (K + wino43::TM - 1) / wino43::TM * wino43::TM;
-    const long long total = (long long)Kpad * C;
+    const int Cpad = (C + wino43::KC - 1) / wino43::KC * wino43::KC;
+    const long long total = (long long)Kpad * Cpad;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(wino43::transform_weights, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), weight, U, K, C,
-                       Kpad, C);
+                       Kpad, Cpad);
     return check_launch("wino43_transform_weights");
 }
 
@@ -693,8 +695,13 @@ static int wino43_forward_impl(const float* const* xs, int nparts, const float* 
                                int W, int act, void* hip_stream, float* ypool = nullptr, const float* addx = nullptr, float* y2 = nullptr) {
     if (!xs || !xs[0] || !U || !bias || !y || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || nparts < 1 || nparts > 4)
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: bad argument (1 to 4 input parts)");
-    if (H % 4 != 0 || W % 4 != 0 || C % nparts != 0 || (C / nparts) % wino43::KC != 0 || act < 0 || act > 2)
-        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: needs H, W and the channels of a part multiples of 4, act in {0, 1, 2}");
+    const int form = g_wino43_waves.load(std::memory_order_relaxed);
+    // one tensor: any C (the transformed weights of the channels past C are zero and the loads of those channels past the tensor's end
+    // return 0; inside it they read the next image's first channels, finite values times zero) -- the generated form only
+    const bool ragged = nparts == 1 && C % wino43::KC != 0;
+    if (H % 4 != 0 || W % 4 != 0 || C % nparts != 0 || (!ragged && (C / nparts) % wino43::KC != 0) || (ragged && (form == 4 || form == 8)) ||
+        act < 0 || act > 2)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: needs H and W multiples of 4, the channels of a part a multiple of 4 (any C for one part), act in {0, 1, 2}");
     if ((long long)N * C * H * W >= (1LL << 29) || (long long)N * K * H * W >= (1LL << 29))
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: tensor too large (2^29 elements or more)");
     if ((y2 && !addx) || (addx && (act != 0 || ypool)) || (ypool && act == 2))
@@ -705,7 +712,7 @@ static int wino43_forward_impl(const float* const* xs, int nparts, const float* 
         p[i] = xs[i];
     }
     const int Kpad = (K + wino43::TM - 1) / wino43::TM * wino43::TM;
-    const int kblocks = Kpad / wino43::TM, nchunks = C / wino43::KC, cpart = C / nparts;
+    const int kblocks = Kpad / wino43::TM, nchunks = (C + wino43::KC - 1) / wino43::KC, cpart = C / nparts;
     const long long tiles = (long long)N * (H / 4) * (W / 4);
     const long long tblocks = (tiles + wino43::TN - 1) / wino43::TN;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
@@ -721,7 +728,7 @@ static int wino43_forward_impl(const float* const* xs, int nparts, const float* 
         auto kern = wino43::conv3x3_gen<A, E>;                                                                                  \
         if (int rc = allow_lds(kern, wino43::LDS_BYTES)) return rc;                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(512), wino43::LDS_BYTES, s, p[0], p[1], p[2], p[3],   \
-                           cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, ypool, addx, y2);                          \
+                           cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, ypool, addx, y2, wino43::Window{});        \
     }
 #ifdef TAI_TIMING_VARIANTS
 #define TAI_W43_LAUNCH_VAR(V)                                                                                                   \
@@ -729,7 +736,7 @@ static int wino43_forward_impl(const float* const* xs, int nparts, const float* 
         auto kern = wino43::conv3x3_gen<1, 0, V>;                                                                               \
         if (int rc = allow_lds(kern, wino43::LDS_BYTES)) return rc;                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(512), wino43::LDS_BYTES, s, p[0], p[1], p[2], p[3],   \
-                           cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, ypool, addx, y2);                          \
+                           cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, ypool, addx, y2, wino43::Window{});        \
         return check_launch("conv3x3_wino43 (ablation)");                                                                       \
     }
     switch (g_wino43_waves.load(std::memory_order_relaxed)) {
@@ -779,6 +786,44 @@ int tai_conv3x3_wino43_forward_ex(const float* const* xs, int nparts, const floa
                                   const float* addx, float* y2, int N, int C, int K, int H, int W, int act, void* hip_stream) {
     g_err[0] = 0;
     return wino43_forward_impl(xs, nparts, U, bias, y, N, C, K, H, W, act, hip_stream, ypool, addx, y2);
+}
+
+int tai_conv3x3_wino43_forward_blocks(const float* x, int shift_k, const float* U, const float* bias, float* y, float* ypool, int pool_h,
+                                      int pool_w, int pool_oy, int pool_ox, int N, int C, int K, int H, int W, int in_h, int in_w, int in_oy,
+                                      int in_ox, int act, void* hip_stream) {
+    g_err[0] = 0;
+    const int S = (shift_k + 2) / 3;
+    if (!x || !U || !bias || !y || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || shift_k < 4 || shift_k > 9 || C % (S * S) != 0 ||
+        (C / (S * S)) % wino43::KC != 0 || H % 4 != 0 || W % 4 != 0 || act < 0 || act > 1)
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43_blocks: bad argument (4 <= shift_k <= 9, C = S^2 x a multiple of 4, H and W multiples of 4, act 0 / 1)");
+    // every read of every block must lie inside the plane: rows in_oy - 1 ... in_oy + H + 3 (S - 1), columns in_ox - 1 ... in_ox + W + 3 (S - 1)
+    if (in_oy < 1 || in_ox < 1 || in_h < in_oy + H + 1 + 3 * (S - 1) || in_w < in_ox + W + 1 + 3 * (S - 1))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43_blocks: the input plane does not carry the halo the displaced reads need");
+    const int cin = C / (S * S);
+    if ((long long)N * cin * in_h * in_w >= (1LL << 29) || (long long)N * K * H * W >= (1LL << 29))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43_blocks: tensor too large (2^29 elements or more)");
+    if (ypool && pool_h > 0 && (pool_w % 2 != 0 || pool_ox % 2 != 0 || pool_oy < 0 || pool_ox < 0 || pool_oy + H / 2 > pool_h || pool_ox + W / 2 > pool_w))
+        return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43_blocks: the pooled-output window must be even in pool_w and pool_ox and lie inside its plane");
+    const int Kpad = (K + wino43::TM - 1) / wino43::TM * wino43::TM;
+    const int kblocks = Kpad / wino43::TM, nchunks = C / wino43::KC;
+    const long long tiles = (long long)N * (H / 4) * (W / 4);
+    const long long tblocks = (tiles + wino43::TN - 1) / wino43::TN;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const wino43::Window win{in_h, in_w, in_oy, in_ox, S, ypool ? pool_h : 0, pool_w, pool_oy, pool_ox};
+#define TAI_W43_LAUNCH_BLOCKS(A, E)                                                                                             \
+    {                                                                                                                           \
+        auto kern = wino43::conv3x3_gen<A, E, 0, true>;                                                                         \
+        if (int rc = allow_lds(kern, wino43::LDS_BYTES)) return rc;                                                             \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(512), wino43::LDS_BYTES, s, x, x, x, x, cin, U, bias, y, N, C, K, H, W, \
+                           Kpad, nchunks, kblocks, ypool, (const float*)nullptr, (float*)nullptr, win);                         \
+    }
+    if (ypool) {
+        if (act == 0) TAI_W43_LAUNCH_BLOCKS(0, 1) else TAI_W43_LAUNCH_BLOCKS(1, 1)
+    } else {
+        if (act == 0) TAI_W43_LAUNCH_BLOCKS(0, 0) else TAI_W43_LAUNCH_BLOCKS(1, 0)
+    }
+#undef TAI_W43_LAUNCH_BLOCKS
+    return check_launch("conv3x3_wino43_blocks");
 }
 
 // Split of the weight-gradient kernel's reduction (the tiles) over workgroups: about one workgroup per CU in total.

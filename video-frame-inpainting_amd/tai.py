@@ -30,7 +30,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .conv_ops import conv_bias_act
+from .conv_ops import conv_bias_act, mark_outside_recurrence
 from .mcnet import IndexedConvs, MCNet, Residual, _conv_relu_chain
 from .separable_convolution import SeparableConvolution
 from .upsample import upsample2x
@@ -197,6 +197,9 @@ class TAIFillInModel(nn.Module):
         self.merge_residual2 = Residual(gf_dim * 4, kf_dim * 2)
         self.merge_residual1 = Residual(gf_dim * 2, kf_dim * 1)   # in the checkpoint schema; output never consumed
         self.kernelnet = TAI(gf_dim, ks, num_block, layers, kf_dim)
+        # outside MC-Net's recurrence: these layers may take the 4 x 4 Winograd tile at any width (conv_ops.mark_outside_recurrence)
+        for m in (self.kernelnet, self.merge_residual1, self.merge_residual2, self.merge_residual3):
+            mark_outside_recurrence(m)
         self.fuse_directions = True
         self.batch_time_steps = True
         self.merge_per_step = True
