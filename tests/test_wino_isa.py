@@ -16,6 +16,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def device_asm(tmp_path_factory):
     if shutil.which('hipcc') is None:
         pytest.skip('hipcc not available')
+    kept = os.path.join(ROOT, 'build', 'sepconv_capi-hip-amdgcn-amd-amdhsa-gfx950.s')      # _native.build() keeps the assembly of its compile
+    lib = os.path.join(ROOT, 'video-frame-inpainting_amd', 'libtai_sepconv.so')
+    if os.path.exists(kept) and os.path.exists(lib) and os.path.getmtime(kept) <= os.path.getmtime(lib) + 1 and \
+            abs(os.path.getmtime(kept) - os.path.getmtime(lib)) < 600:
+        from video_frame_inpainting_amd import _native
+        if _native.embedded_source_hash(lib) == _native.source_hash():
+            return open(kept).read()
     out = tmp_path_factory.mktemp('isa') / 'capi.s'
     cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-w', '-I' + os.path.join(ROOT, 'include'),
            '--cuda-device-only', '-S', os.path.join(ROOT, 'video-frame-inpainting_amd', 'csrc', 'sepconv_capi.hip'), '-o', str(out)]
@@ -219,3 +226,24 @@ def test_wino43_kernel_has_no_spills_and_keeps_its_mfma_count(device_asm):
         dma = sum(1 for l in lines if 'global_load_lds_dwordx4' in l)
         assert dma == 18, (name, dma)          # nine in the prologue, nine in the chunk loop
     assert found >= 8              # <ACT 0..2> x <4 | 8 waves> plain, + the pooled / unpool-add epilogues of the eight-wave form
+
+
+def test_build_time_invariants_hold_and_catch_a_broken_compile(device_asm):
+    """video-frame-inpainting_amd/_isa_check.py (run by _native.build on the assembly of the compile that produces the library): clean on the
+    real assembly; a scratch access in the generated-loop kernel, a read of an asm-loaded register before its wait in the round-4 form and
+    a missing MFMA are each reported."""
+    from video_frame_inpainting_amd import _isa_check
+    assert _isa_check.check(device_asm) == []
+    gen = next(iter(_isa_check.kernels(device_asm, '_ZN6wino4311conv3x3_gen')))
+    i = device_asm.find(gen + ':')
+    j = device_asm.find('v_mfma_f32_16x16x4_f32', i)
+    doctored = device_asm[:j] + 'scratch_store_dword off, v5, off\n\t' + device_asm[j:]
+    assert any('scratch' in v for v in _isa_check.check(doctored))
+    k = device_asm.find('\n', j)
+    assert any('MFMAs' in v for v in _isa_check.check(device_asm[:j] + 's_nop 0' + device_asm[k:]))
+    old = next(iter(_isa_check.kernels(device_asm, '_ZN6wino437conv3x3ILi1ELb1ELi0EE')))
+    a = device_asm.find(old + ':')
+    m = re.compile(r'buffer_load_dword v(\d+), v\d+, s\[\d+:\d+\], s\d+ offen\n\t;;#ASMEND\n').search(device_asm, a)
+    assert m is not None
+    copy = '\tv_mov_b32_e32 v1, v%s\n' % m.group(1)
+    assert any('before the wait' in v for v in _isa_check.check(device_asm[:m.end()] + copy + device_asm[m.end():]))

@@ -77,8 +77,13 @@ def build(force=False, verbose=False, timing=False):
     # that survived a failed rebuild); the new one is written beside the target and renamed over it only when hipcc succeeded
     if os.path.exists(out):
         os.remove(out)
-    tmp = out + '.building.%d' % os.getpid()
-    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-slp-vectorize', '-w',
+    # compiled in a directory of its own with -save-temps=obj: the device assembly of THIS compile is checked before the library is
+    # installed (_isa_check: properties of the generated code that a different hipcc could break with no source change)
+    import shutil
+    work = os.path.join(_ROOT, 'build', 'obj.%s.%d' % ('timing' if timing else 'lib', os.getpid()))
+    os.makedirs(work, exist_ok=True)
+    tmp = os.path.join(work, os.path.basename(out))
+    cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-fno-slp-vectorize', '-w', '-save-temps=obj',
            '-I' + os.path.join(_ROOT, 'include'), '-DTAI_SOURCE_HASH="%s"' % want, '-o', tmp, MAIN_SOURCE] + \
           (['-DTAI_TIMING_VARIANTS'] if timing else [])
     if verbose:
@@ -87,10 +92,17 @@ def build(force=False, verbose=False, timing=False):
         subprocess.check_call(cmd)
         if source_hash() != want:
             raise NativeLibraryError('csrc/ changed while %s was compiling: build again' % os.path.basename(out))
+        asm = os.path.join(work, 'sepconv_capi-hip-amdgcn-amd-amdhsa-gfx950.s')
+        from . import _isa_check
+        violations = _isa_check.check(open(asm).read())
+        if violations:
+            raise NativeLibraryError('the device code hipcc generated for %s breaks an invariant the kernels rely on; the library is NOT '
+                                     'installed:\n  %s' % (os.path.basename(out), '\n  '.join(violations[:20])))
+        if not timing:          # kept for tools/isa_fn.py and a look at what the compiler did
+            os.replace(asm, os.path.join(_ROOT, 'build', 'sepconv_capi-hip-amdgcn-amd-amdhsa-gfx950.s'))
         os.replace(tmp, out)
     finally:
-        if os.path.exists(tmp):
-            os.remove(tmp)
+        shutil.rmtree(work, ignore_errors=True)
     return out
 
 
