@@ -446,10 +446,14 @@ def test_wino_weight_gradient_declines_unsupported_shapes():
 
 @pytest.mark.parametrize('k,shape', [(5, (16, 64, 128, 64, 64)), (7, (16, 128, 256, 32, 32))])
 @pytest.mark.parametrize('act', [None, 'relu'])
-def test_5x5_and_7x7_training_form_gradients_match_autograd_of_conv2d(k, shape, act):
-    """MotionEnc's 5x5 / 7x7 layers under autograd: forward and input gradient through the Winograd kernel over shifted
-    copies (the input gradient with the transposed, flipped filter), weight / bias gradients from MIOpen / a sum."""
+@pytest.mark.parametrize('tile', [2, 4])
+def test_5x5_and_7x7_training_form_gradients_match_autograd_of_conv2d(k, shape, act, tile, monkeypatch):
+    """MotionEnc's 5x5 / 7x7 layers under autograd: forward and input gradient through the Winograd kernel -- F(2x2, 3x3) over shifted
+    copies, or (tile 4, the default) F(4x4, 3x3) blocks displaced over a halo plane -- the input gradient with the transposed, flipped
+    filter; weight / bias gradients from the Winograd-domain weight-gradient kernel over the stack of shifted copies."""
     from video_frame_inpainting_amd import conv_ops
+    monkeypatch.setattr(conv_ops, 'WINO43_UNDER_AUTOGRAD', tile == 4)
+    monkeypatch.setattr(conv_ops, 'WINO43_MIN_WORKGROUPS', 1)          # (these 16-image shapes are below the dispatch threshold)
     N, C, K, H, W = shape
     g = torch.Generator().manual_seed(k * 10 + H)
     x = torch.randn(N, C, H, W, generator=g).cuda().requires_grad_(True)
@@ -459,14 +463,15 @@ def test_5x5_and_7x7_training_form_gradients_match_autograd_of_conv2d(k, shape, 
     y = conv_ops.conv_bias_act(x, w, b, k // 2, act)
     assert type(y.grad_fn).__name__ == '_WinoConvKxKBackward'
     gx, gw, gb = torch.autograd.grad(y, (x, w, b), go)
-    assert ('wino_kxk', True) in w._tai_derived
+    assert (('wino43_kxk', True) if tile == 4 else ('wino_kxk', True)) in w._tai_derived
+    assert (('wino43_kxk', False) if tile == 4 else ('wino_kxk', False)) in w._tai_derived
     xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
     yd = F.conv2d(xd, wd, bd, padding=k // 2)
     # the ReLU's mask is taken from the fp32 output: a pre-activation within rounding of zero (there are a few among the
     # 4M outputs of 6,272-term sums) may open in one precision and not in the other, and that is not what is tested here
     yd = yd * (y.detach() > 0) if act == 'relu' else yd
     rx, rw, rb = torch.autograd.grad(yd, (xd, wd, bd), go.double())
-    for got, ref, tol in ((y, yd, 1e-5), (gx, rx, 2e-4), (gw, rw, 2e-4), (gb, rb, 2e-4)):
+    for got, ref, tol in ((y, yd, 1e-5 if tile == 2 else 6e-5), (gx, rx, 2e-4), (gw, rw, 2e-4), (gb, rb, 2e-4)):
         err = (got.double() - ref).abs().max().item() / (1 + ref.abs().max().item())
         assert err <= tol, err
 

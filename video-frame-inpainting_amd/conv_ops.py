@@ -68,7 +68,8 @@ def get_winograd_arithmetic():
 
 _WINO_TILE = [4]
 WINO43_MIN_CHANNELS = 128        # F(4x4, 3x3) only where both C and K are at least this (profiles/r04_wino_f43_study.txt: parity-neutral there)
-WINO43_MIN_WORKGROUPS = 400      # ... and where its 64-channel x 32-tile workgroups fill the chip at least ~1.6 times over
+WINO43_MIN_WORKGROUPS = 150      # ... and where its 64-channel x 32-tile workgroups occupy most of the chip (round 5's kernel, same box, the
+                                 # replayed configs[1] forward: 400: 51.11 ms, 256: 50.78, 150: 50.57, 100: 51.32, 64: 51.75 -- tools/w43_threshold_ab.py)
 
 
 def set_winograd_tile(m):
@@ -176,10 +177,12 @@ def _wino_weights_kxk(weight, transposed=False):
     return _cached(weight, ('wino_kxk', transposed), make)
 
 
-def _wino43_weights_kxk(weight):
-    """The k x k filter as S x S blocks of 3 x 3 taps in the F(4x4, 3x3) layout (tai_conv3x3_wino43_forward_blocks)."""
+def _wino43_weights_kxk(weight, transposed=False):
+    """The k x k filter as S x S blocks of 3 x 3 taps in the F(4x4, 3x3) layout (tai_conv3x3_wino43_forward_blocks); ``transposed``: the
+    filter of the input-gradient convolution, weight[k, c, a, b] -> [c, k, K-1-a, K-1-b]."""
     def make():
-        w = _block3x3_weight(weight.detach())
+        w = weight.detach()
+        w = _block3x3_weight(w.transpose(0, 1).flip(2, 3).contiguous() if transposed else w)
         K, C = w.shape[0], w.shape[1]
         L = _native.lib()
         U = torch.empty(L.tai_conv3x3_wino43_weight_floats(K, C), dtype=torch.float32, device=w.device)
@@ -188,7 +191,7 @@ def _wino43_weights_kxk(weight):
                                                                  torch.cuda.current_stream(w.device).cuda_stream),
                           'tai_conv3x3_wino43_transform_weights')
         return U
-    return _cached(weight, ('wino43_kxk',), make)
+    return _cached(weight, ('wino43_kxk', transposed), make)
 
 
 def _wino43_blocks_ok(N, Cin, Co, H, W):
@@ -196,6 +199,23 @@ def _wino43_blocks_ok(N, Cin, Co, H, W):
     measured parity-neutral too (profiles/r05_wino_f43_policy_study.txt: "big + MotionEnc 5x5")."""
     return (_WINO_TILE[0] == 4 and Cin % 4 == 0 and Cin >= 16 and H % 4 == 0 and W % 4 == 0
             and ((N * (H // 4) * (W // 4) + 31) // 32) * ((Co + 63) // 64) >= WINO43_MIN_WORKGROUPS)
+
+
+def _kxk_as_blocks(x, weight, bias, act, transposed=False):
+    """5x5 / 7x7 "same" convolution on the 4 x 4 tile: x copied into a zero-haloed plane, read S x S times by displaced 3 x 3 blocks
+    (tai_conv3x3_wino43_forward_blocks).  The training form's forward and input gradient (``transposed``)."""
+    N, C, H, W = x.shape
+    K, k = weight.shape[1 if transposed else 0], weight.shape[2]
+    S, top, left, in_h, in_w = halo_geometry(H, W, k)
+    plane = halo_plane(N, C, H, W, k, x.device)
+    plane[:, :, top:top + H, left:left + W].copy_(x)
+    y = torch.empty((N, K, H, W), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _native.check(_native.lib().tai_conv3x3_wino43_forward_blocks(
+            plane.data_ptr(), k, _wino43_weights_kxk(weight, transposed).data_ptr(), bias.data_ptr(), y.data_ptr(), None, 0, 0, 0, 0,
+            N, S * S * C, K, H, W, in_h, in_w, 1, 2, _ACT[act], torch.cuda.current_stream(x.device).cuda_stream),
+            'tai_conv3x3_wino43_forward_blocks')
+    return y
 
 
 def _kxk_as_wino(x, weight, bias, act, pool, transposed=False, keep_stack=False):
@@ -398,6 +418,24 @@ def _wino_launch(x, U, bias, N, Ci, Co, H, W, act):
     return y
 
 
+# Under autograd the forward and the input gradient (the same convolution with the weight transposed and flipped) take the 4 x 4 tile on
+# the layers the inference path gives it: the training forward then runs the arithmetic of the inference forward (False: F(2x2, 3x3)
+# for everything under autograd, as in rounds 2-4)
+WINO43_UNDER_AUTOGRAD = True
+
+
+def _conv3x3_autograd_launch(x, weight, eff_transposed, bias, N, Ci, Co, H, W, act):
+    """conv(x, w_eff) with w_eff = the weight in orientation ``eff_transposed``: F(4x4, 3x3) where _wino43_ok says so, else F(2x2, 3x3)."""
+    if WINO43_UNDER_AUTOGRAD and _wino43_ok(N, Ci, Co, H, W, 1, weight):
+        y = torch.empty((N, Co, H, W), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _native.check(_native.lib().tai_conv3x3_wino43_forward(x.data_ptr(), _wino43_weights(weight, eff_transposed).data_ptr(), bias.data_ptr(),
+                                                                  y.data_ptr(), N, Ci, Co, H, W, _ACT[act],
+                                                                  torch.cuda.current_stream(x.device).cuda_stream), 'tai_conv3x3_wino43_forward')
+        return y
+    return _wino_launch(x, _wino_weights(weight, eff_transposed), bias, N, Ci, Co, H, W, act)
+
+
 _ZERO_BIAS = {}
 
 
@@ -473,7 +511,7 @@ class _WinoConv3x3(torch.autograd.Function):
         x = x.contiguous()
         Co, Ci = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
         N, _, H, W = x.shape
-        y = _wino_launch(x, _wino_weights(weight, transposed), bias, N, Ci, Co, H, W, act)
+        y = _conv3x3_autograd_launch(x, weight, transposed, bias, N, Ci, Co, H, W, act)
         ctx.act, ctx.transposed = act, transposed
         ctx.save_for_backward(x, weight, y if act is not None else None)
         return y
@@ -492,7 +530,7 @@ class _WinoConv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # d/dx of conv(x, w_eff) is conv(g, w_eff transposed and flipped): the other orientation of the same weight
             zero = _zero_bias(Ci, g.device)
-            gx = _wino_launch(g, _wino_weights(weight, not ctx.transposed), zero, N, Co, Ci, H, W, None)
+            gx = _conv3x3_autograd_launch(g, weight, not ctx.transposed, zero, N, Co, Ci, H, W, None)
         if ctx.needs_input_grad[1]:
             gw_eff = None
             if g.dtype == torch.float32 and x.dtype == torch.float32:
@@ -528,13 +566,17 @@ class _WinoConv3x3Parts(torch.autograd.Function):
         Co, Ci = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
         N, Cp, H, W = x0.shape
         L = _native.lib()
-        U = _wino_weights(weight, transposed)
         y = torch.empty((N, Co, H, W), dtype=x0.dtype, device=x0.device)
         ptrs = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
         with torch.cuda.device(x0.device):
-            _native.check(L.tai_conv3x3_wino_forward_parts(ptrs, len(parts), U.data_ptr(), bias.data_ptr(), y.data_ptr(), N, Ci, Co, H, W,
-                                                           _ACT[act], torch.cuda.current_stream(x0.device).cuda_stream),
-                          'tai_conv3x3_wino_forward_parts')
+            if WINO43_UNDER_AUTOGRAD and _wino43_ok(N, Ci, Co, H, W, len(parts), weight):
+                _native.check(L.tai_conv3x3_wino43_forward_parts(ptrs, len(parts), _wino43_weights(weight, transposed).data_ptr(), bias.data_ptr(),
+                                                                 y.data_ptr(), N, Ci, Co, H, W, _ACT[act],
+                                                                 torch.cuda.current_stream(x0.device).cuda_stream), 'tai_conv3x3_wino43_forward_parts')
+            else:
+                _native.check(L.tai_conv3x3_wino_forward_parts(ptrs, len(parts), _wino_weights(weight, transposed).data_ptr(), bias.data_ptr(),
+                                                               y.data_ptr(), N, Ci, Co, H, W, _ACT[act],
+                                                               torch.cuda.current_stream(x0.device).cuda_stream), 'tai_conv3x3_wino_forward_parts')
         ctx.act, ctx.transposed, ctx.nparts = act, transposed, len(parts)
         ctx.save_for_backward(weight, y if act is not None else None, *parts)
         return y
@@ -553,8 +595,16 @@ class _WinoConv3x3Parts(torch.autograd.Function):
         gparts = [None] * n
         for i in range(n):
             if ctx.needs_input_grad[4 + i]:
-                gparts[i] = _wino_launch(g, _wino_weights_input_grad_part(weight, ctx.transposed, i, n), _zero_bias(Cp, g.device),
-                                         N, Co, Cp, H, W, None)
+                if WINO43_UNDER_AUTOGRAD and _wino43_ok(N, Co, Cp, H, W, 1, weight):
+                    gparts[i] = torch.empty((N, Cp, H, W), dtype=g.dtype, device=g.device)
+                    with torch.cuda.device(g.device):
+                        _native.check(_native.lib().tai_conv3x3_wino43_forward(
+                            g.data_ptr(), _wino_weights_input_grad_part(weight, ctx.transposed, i, n, tile=4).data_ptr(),
+                            _zero_bias(Cp, g.device).data_ptr(), gparts[i].data_ptr(), N, Co, Cp, H, W, 0,
+                            torch.cuda.current_stream(g.device).cuda_stream), 'tai_conv3x3_wino43_forward')
+                else:
+                    gparts[i] = _wino_launch(g, _wino_weights_input_grad_part(weight, ctx.transposed, i, n), _zero_bias(Cp, g.device),
+                                             N, Co, Cp, H, W, None)
         gw = gb = None
         if ctx.needs_input_grad[0]:
             want_bias = ctx.needs_input_grad[1]
@@ -579,22 +629,23 @@ class _WinoConv3x3Parts(torch.autograd.Function):
         return (gw, gb, None, None) + tuple(gparts)
 
 
-def _wino_weights_input_grad_part(weight, transposed, i, nparts):
+def _wino_weights_input_grad_part(weight, transposed, i, nparts, tile=2):
     """Transformed weights of the input-gradient convolution of channel part ``i`` of ``nparts``: conv(g, w_i transposed and flipped)
-    with w_i the slice of the layer's effective weight [Co, Ci, 3, 3] over that part's input channels."""
+    with w_i the slice of the layer's effective weight [Co, Ci, 3, 3] over that part's input channels; ``tile`` 2 / 4: the F(2x2, 3x3) /
+    F(4x4, 3x3) layout."""
     def make():
         w_eff = _as_conv_weight(weight.detach(), transposed)                              # [Co, Ci, 3, 3]
         Cp = w_eff.shape[1] // nparts
         w = w_eff[:, i * Cp:(i + 1) * Cp].transpose(0, 1).flip(2, 3).contiguous()          # [Cp, Co, 3, 3]
         K, C = w.shape[0], w.shape[1]
         L = _native.lib()
-        U = torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), dtype=torch.float32, device=w.device)
+        pre = 'tai_conv3x3_wino43' if tile == 4 else 'tai_conv3x3_wino'
+        U = torch.empty(getattr(L, pre + '_weight_floats')(K, C), dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
-            _native.check(L.tai_conv3x3_wino_transform_weights(w.data_ptr(), U.data_ptr(), K, C,
-                                                               torch.cuda.current_stream(w.device).cuda_stream),
-                          'tai_conv3x3_wino_transform_weights')
+            _native.check(getattr(L, pre + '_transform_weights')(w.data_ptr(), U.data_ptr(), K, C, torch.cuda.current_stream(w.device).cuda_stream),
+                          pre + '_transform_weights')
         return U
-    return _cached(weight, ('wino_input_grad_part', transposed, i, nparts), make)
+    return _cached(weight, ('wino_input_grad_part', transposed, i, nparts, tile), make)
 
 
 class _WinoConvKxK(torch.autograd.Function):
@@ -605,15 +656,24 @@ class _WinoConvKxK(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act):
         x = x.contiguous()
-        y, stack = _kxk_as_wino(x, weight, bias, act, False, keep_stack=True)
+        N, Ci, H, W = x.shape
+        Co = weight.shape[0]
         ctx.act = act
+        if WINO43_UNDER_AUTOGRAD and act in (None, 'relu') and _wino43_blocks_ok(N, Ci, Co, H, W):
+            # the 4 x 4 tile over a halo plane; the stack of shifted copies the weight gradient reads is built in the backward pass
+            # (134 / 151 MB per MotionEnc call no longer kept from forward to backward)
+            y = _kxk_as_blocks(x, weight, bias, act)
+            ctx.save_for_backward(x, weight, y if act is not None else None)
+            return y
+        y, stack = _kxk_as_wino(x, weight, bias, act, False, keep_stack=True)
         # the stack of shifted copies (S*S times the input) is kept for the weight gradient: 134 / 151 MB per MotionEnc call
         ctx.save_for_backward(x, weight, y if act is not None else None, stack)
         return y
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, weight, y, stack = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        x, weight, y = saved[0], saved[1], saved[2]
         g = grad_out.contiguous()
         if ctx.act == 'relu':
             g = torch.ops.aten.threshold_backward(g, y, 0)
@@ -622,8 +682,20 @@ class _WinoConvKxK(torch.autograd.Function):
         Co, Ci, k = weight.shape[0], weight.shape[1], weight.shape[2]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _kxk_as_wino(g, weight, _zero_bias(Ci, g.device), None, False, transposed=True)
+            if WINO43_UNDER_AUTOGRAD and _wino43_blocks_ok(g.shape[0], Co, Ci, g.shape[2], g.shape[3]):
+                gx = _kxk_as_blocks(g, weight, _zero_bias(Ci, g.device), None, transposed=True)
+            else:
+                gx = _kxk_as_wino(g, weight, _zero_bias(Ci, g.device), None, False, transposed=True)
         if ctx.needs_input_grad[1]:
+            if len(saved) > 3:
+                stack = saved[3]
+            else:
+                N, _, H, W = x.shape
+                S = (k + 2) // 3
+                stack = torch.empty((N, S * S * Ci, H + 2, W + 4), dtype=x.dtype, device=x.device)
+                with torch.cuda.device(x.device):
+                    _native.check(_native.lib().tai_conv_shift_stack(x.data_ptr(), stack.data_ptr(), N, Ci, H, W, k,
+                                                                     torch.cuda.current_stream(x.device).cuda_stream), 'tai_conv_shift_stack')
             # the weight gradient of the blocked 3x3 form over the stack (it carries its halo: origin (1, 2)), then un-blocked
             both = wino_weight_grad(stack, g, with_bias=True, window=(1, 2))
             if both is not None:
