@@ -234,13 +234,20 @@ def sepconv_in_model_roofline(device, B, reps=10):
 # (N, C, K, H, W, calls per forward) of the 3x3 convolutions of configs[1] (TAI_gray, 32 clips: both directions batched to
 # 64, the five kernel-network evaluations batched to 160), profiles/r01_conv_path_times.txt; the 5x5 / 7x7 layers appear
 # in the form the kernel sees them (4 / 9 shifted copies stacked on the channels).
-# (N, C, K, H, W, launches per step[, True: a 5x5 / 7x7 layer cut into 3x3 blocks -- displaced reads, F(2x2, 3x3) whatever its width])
+# (N, C, K, H, W, launches per step[, kind]); kind 'kxk': a 5x5 / 7x7 MotionEnc layer cut into 3x3 blocks (displaced reads; timed here as the
+# plain 3x3 layer over the S x S channel blocks: the same MFMAs); 'any': a layer outside MC-Net's recurrence (kernel network, merge
+# residuals: conv_ops.mark_outside_recurrence), which takes F(4x4, 3x3) at any width
 CONV_LAYERS = ((64, 64, 64, 128, 128, 15), (64, 128, 64, 128, 128, 5), (64, 64, 128, 64, 64, 5), (64, 128, 128, 64, 64, 15),
-               (64, 256, 128, 64, 64, 8, True), (64, 256, 128, 64, 64, 5), (64, 128, 256, 32, 32, 5), (64, 256, 256, 32, 32, 25),
-               (64, 512, 256, 32, 32, 5), (64, 1152, 256, 32, 32, 8, True), (64, 512, 1024, 16, 16, 8), (64, 512, 256, 16, 16, 5),
-               (160, 51, 51, 128, 128, 4), (160, 64, 64, 64, 64, 9), (160, 64, 51, 64, 64, 4), (160, 256, 64, 64, 64, 1),
-               (160, 512, 128, 32, 32, 1), (160, 1024, 256, 16, 16, 1), (160, 256, 256, 16, 16, 3))
+               (64, 256, 128, 64, 64, 8, 'kxk'), (64, 256, 128, 64, 64, 5), (64, 128, 256, 32, 32, 5), (64, 256, 256, 32, 32, 25),
+               (64, 512, 256, 32, 32, 5), (64, 1152, 256, 32, 32, 8, 'kxk'), (64, 512, 1024, 16, 16, 8), (64, 512, 256, 16, 16, 5),
+               (160, 51, 51, 128, 128, 4, 'any'), (160, 64, 64, 64, 64, 9, 'any'), (160, 64, 51, 64, 64, 4, 'any'), (160, 256, 64, 64, 64, 1, 'any'),
+               (160, 512, 128, 32, 32, 1, 'any'), (160, 1024, 256, 16, 16, 1, 'any'), (160, 256, 256, 16, 16, 3, 'any'))
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA
+
+
+def conv_ops_threshold():
+    from video_frame_inpainting_amd import conv_ops
+    return conv_ops.WINO43_MIN_WORKGROUPS
 
 
 def conv_roofline(device):
@@ -252,14 +259,17 @@ def conv_roofline(device):
     per_graph = 8
     with torch.no_grad():
         for layer in CONV_LAYERS:
-            (N, C, K, H, W, calls), kxk = layer[:6], len(layer) > 6
+            (N, C, K, H, W, calls), kind = layer[:6], (layer[6] if len(layer) > 6 else '')
             g = torch.Generator().manual_seed(N + C + K)
             x = torch.randn(N, C, H, W, generator=g).to(device)
             w = (torch.randn(K, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).to(device)
             b = torch.zeros(K, device=device)
             y = torch.empty(N, K, H, W, device=device)
-            # the kernel conv_ops dispatches this layer to: F(4x4, 3x3) on the wide layers (C, K >= 128, enough workgroups), else F(2x2, 3x3)
-            f43 = conv_ops._wino43_ok(N, C, K, H, W) and not kxk
+            # the kernel conv_ops dispatches this layer to: F(4x4, 3x3) on the wide layers (C, K >= 128), on the layers outside MC-Net's
+            # recurrence and on MotionEnc's blocks -- each with enough workgroups -- else F(2x2, 3x3)
+            if kind == 'any':
+                w._tai_f43_any_width = True
+            f43 = conv_ops._wino43_blocks_ok(N, C, K, H, W) if kind == 'kxk' else conv_ops._wino43_ok(N, C, K, H, W, 1, w)
             pre = 'tai_conv3x3_wino43' if f43 else 'tai_conv3x3_wino'
             U = torch.empty(getattr(L, pre + '_weight_floats')(K, C), device=device)
             _native.check(getattr(L, pre + '_transform_weights')(w.data_ptr(), U.data_ptr(), K, C, stream), 'transform_weights')
@@ -289,7 +299,7 @@ def conv_roofline(device):
     achieved = mfma_flops / seconds / 1e12
     return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
-            'kernel': 'wino::conv3x3 (F(2x2,3x3)) and wino43::conv3x3 (F(4x4,3x3), the wide layers), fp32 MFMA, as conv_ops dispatches them',
+            'kernel': 'wino::conv3x3 (F(2x2,3x3)) and wino43::conv3x3_gen (F(4x4,3x3): the wide layers, the layers outside the recurrence, MotionEnc), fp32 MFMA, as conv_ops dispatches them',
             'layers': len(CONV_LAYERS), 'launches_per_step': sum(l[5] for l in CONV_LAYERS), 'ms_per_step_in_kernel': round(seconds * 1e3, 2),
             'launches_per_step_f43': n43, 'ms_per_step_in_kernel_f43': round(s43 * 1e3, 2),
             'direct_conv_tflops': round(direct_flops / seconds / 1e12, 1),
@@ -490,10 +500,10 @@ def secondary_configs(device, parity=True):
 
     optin_leg('configs[1], split-bf16 Winograd arithmetic (opt-in)',
               'fp32 operands as hi + mid + lo bf16 terms, 6 of the 9 bf16 products, fp32 accumulate (v_mfma_f32_32x32x16_bf16); '
-              'layers the split kernel does not take (5x5 / 7x7 displaced reads; the wide layers, which run F(4x4,3x3)) stay on the fp32 MFMA',
+              'layers the split kernel does not take (the layers that run F(4x4,3x3)) stay on the fp32 MFMA',
               lambda: conv_ops.set_winograd_arithmetic('bf16x3'), conv_ops.set_winograd_arithmetic)
     optin_leg('configs[1], Winograd F(2x2,3x3) on every layer (the arithmetic of rounds 1-3, for reference)',
-              'fp32 on the fp32 MFMA; the headline runs the layers with C >= 128 and K >= 128 and >= 400 workgroups as F(4x4,3x3) instead',
+              'fp32 on the fp32 MFMA; the headline runs the wide layers, the kernel network, the merge residuals and MotionEnc as F(4x4,3x3) instead',
               lambda: conv_ops.set_winograd_tile(2), conv_ops.set_winograd_tile)
     # the three-channel sepconv forward at configs[3]'s launch shape [T*B = 80, 3, 256, 256] would be 2.3 GB of taps; the
     # per-time-step shape [16,3,256,256] is the one SURVEY.md 8(a) tabulates
@@ -850,8 +860,9 @@ def main():
                    'clips_per_gpu': B, 'global_clips': world * B, 'parallelism': 'clip-sharded x%d, no collective' % world,
                    'ranks': world, 'backend': ('rccl (torch.distributed "nccl")' if backend == 'nccl' else backend),
                    'weights': 'seeded N(0, 1/fan_in) weights and N(0, 0.01) biases (synthetic.seeded_init, seed %d)' % WEIGHT_SEED,
-                   'convolutions': 'fp32 on the fp32 MFMA: Winograd F(4x4,3x3) on the 3x3 layers with C >= 128 and K >= 128 (and >= 400 '
-                                   'workgroups), F(2x2,3x3) on the others and on the 5x5 / 7x7 layers (conv_ops.set_winograd_tile)'},
+                   'convolutions': 'fp32 on the fp32 MFMA: Winograd F(4x4,3x3) on the 3x3 layers with C >= 128 and K >= 128, on every layer of the '
+                                   'kernel network and the merge residuals and on the 5x5 / 7x7 MotionEnc layers as 3x3 blocks (each with '
+                                   '>= %d workgroups), F(2x2,3x3) on the others (conv_ops.set_winograd_tile)' % conv_ops_threshold()},
     }
     if args.rehearse_one_gpu:
         line['rehearsal'] = 'all %d ranks on one GPU, gloo control plane: NOT a measurement' % world

@@ -65,6 +65,7 @@ S_SOFF, S_LEFT, S_REM = 68, 69, 70
 S_WP = 72
 S_DST_OTHER, S_DST_THIS, S_T = 74, 75, 76
 S_NEXT = 78                               # s[78:83]: bases of parts 1..3, rotated down at every part switch (even: s_mov_b64)
+S_MB_LEFT, S_MB_COL, S_MB_ROW, S_FLAGS = 84, 85, 86, 87     # displaced-read form: the block the MFMA phase is in, and its zero-tap flags
 
 NEG5 = '0xc0a00000'
 BLOCKS = [False]       # generate the displaced-read form (k x k filters as S x S blocks of 3 x 3 taps: see emit_patch_advance)
@@ -101,11 +102,25 @@ def emit_read(e, g, buf):
     e('ds_read_b128 %s, v%d offset:%d', quad(B_BUF[buf]), V_RB, g * KC * TN * 16)
 
 
+def position_ij(p):
+    """inverse of position(): transform-domain (row, column) of position p"""
+    q = p >> 1
+    return (q // 6) * 2 + (p & 1), q % 6
+
+
+SKIP_N = [0]
+
+
 def emit_mfma_phase(e, extra=None):
     """36 MFMAs on the current stage.  The operands of groups 0 and 1 were requested just before (buffers 0, 1; nothing else on lgkmcnt
     behind them); group g + 2 is requested while group g runs.  `extra(g)` emits what the role interleaves in front of group g's MFMAs
     (vector-memory instructions of the next chunk: issued all at once behind the barrier they queue at the CU's one address unit and
-    block the wave's MFMAs behind them)."""
+    block the wave's MFMAs behind them).
+    Displaced-read form: a k x k filter cut into 3 x 3 blocks is zero past k, so in the LAST block row (column) the third tap row (column)
+    is all zeros and with it, exactly, row (column) 5 of that block's 6 x 6 transformed weights (G's last row picks the third tap): those
+    MFMAs multiply by zeros and are skipped -- s87 bit 0: last block row (positions (5, j)), bit 1: last block column (positions (i, 5)) --
+    by forward branches that fall through when nothing is skipped.  Within a group the always-issued MFMAs go first; every accumulator
+    keeps its own summation order, so the results do not change."""
     for g in range(9):
         if g < 7:
             emit_read(e, g + 2, (g + 2) % 3)
@@ -113,9 +128,58 @@ def emit_mfma_phase(e, extra=None):
             extra(g)
         e('s_waitcnt lgkmcnt(%d)', 4 if g < 7 else (2 if g == 7 else 0))
         buf = g % 3
-        for j in range(0 if 'nomfma' in ABLATE else 4):
-            p = 4 * g + j
-            e('v_mfma_f32_16x16x4_f32 a[%d:%d], v%d, v%d, a[%d:%d]', 4 * p, 4 * p + 3, A_BUF[buf] + j, B_BUF[buf] + j, 4 * p, 4 * p + 3)
+        if 'nomfma' in ABLATE:
+            continue
+        kinds = {}
+        for j in range(4):
+            i5, j5 = position_ij(4 * g + j)
+            kinds.setdefault((i5 == 5, j5 == 5) if BLOCKS[0] else (False, False), []).append(j)
+        for kind in ((False, False), (True, False), (False, True), (True, True)):
+            if kind not in kinds:
+                continue
+            label = None
+            if kind != (False, False):
+                SKIP_N[0] += 1
+                label = 'SKIP%d' % SKIP_N[0]
+                if kind == (True, True):
+                    e('s_cmp_lg_u32 s%d, 0', S_FLAGS)
+                else:
+                    e('s_bitcmp1_b32 s%d, %d', S_FLAGS, 0 if kind[0] else 1)
+                e('s_cbranch_scc1 %s', e.ref(label))
+            for j in kinds[kind]:
+                p = 4 * g + j
+                e('v_mfma_f32_16x16x4_f32 a[%d:%d], v%d, v%d, a[%d:%d]', 4 * p, 4 * p + 3, A_BUF[buf] + j, B_BUF[buf] + j, 4 * p, 4 * p + 3)
+            if label:
+                e.label(label)
+
+
+def emit_block_flags_advance(e, tag):
+    """displaced-read form, end of a chunk's MFMA phase: which block is the next chunk in?  (s84 chunks left in the block, s85 / s86 blocks
+    left in the block row / block rows left, the current one included; s54 = 1 where the filter leaves zero taps: 3 S > k.)"""
+    if not BLOCKS[0]:
+        return
+    e('s_sub_u32 s%d, s%d, 1', S_MB_LEFT, S_MB_LEFT)
+    e('s_cmp_lg_u32 s%d, 0', S_MB_LEFT)
+    e('s_cbranch_scc1 %s', e.ref('SAMEBLOCK_' + tag))
+    e('s_mov_b32 s%d, s%d', S_MB_LEFT, S_CPP)
+    e('s_sub_u32 s%d, s%d, 1', S_MB_COL, S_MB_COL)
+    e('s_cmp_lg_u32 s%d, 0', S_MB_COL)
+    e('s_cbranch_scc1 %s', e.ref('SAMEROW_' + tag))
+    e('s_mov_b32 s%d, s%d', S_MB_COL, S_PART(2)[0])
+    e('s_sub_u32 s%d, s%d, 1', S_MB_ROW, S_MB_ROW)
+    e.label('SAMEROW_' + tag)
+    emit_block_flags(e)
+    e.label('SAMEBLOCK_' + tag)
+
+
+def emit_block_flags(e):
+    e('s_cmp_eq_u32 s%d, 1', S_MB_ROW)
+    e('s_cselect_b32 s%d, 1, 0', S_FLAGS)
+    e('s_cmp_eq_u32 s%d, 1', S_MB_COL)
+    e('s_cselect_b32 s%d, 2, 0', S_T)
+    e('s_or_b32 s%d, s%d, s%d', S_FLAGS, S_FLAGS, S_T)
+    e('s_cmp_lg_u32 s%d, 0', S_PART(3)[0])                    # zero taps at all?
+    e('s_cselect_b32 s%d, s%d, 0', S_FLAGS, S_FLAGS)
 
 
 def emit_patch_row_load(e, r):
@@ -310,6 +374,7 @@ def emit_role(e, role):
         emit_mfma_phase(e)
         e.label('CHUNK_END_' + tag)
         e('s_waitcnt vmcnt(0)')
+    emit_block_flags_advance(e, tag)
     if 'nobarrier' not in ABLATE:
         e('s_barrier')
     emit_toggle(e, patch)
@@ -357,6 +422,10 @@ def generate():
     if BLOCKS[0]:
         e('s_mov_b32 s%d, 0', S_NEXT)                            # displacement of block (0, 0)
         e('s_mov_b32 s%d, s%d', S_NEXT + 2, S_PART(2)[0])       # blocks left in the block row: S
+        e('s_mov_b32 s%d, s%d', S_MB_LEFT, S_CPP)               # the MFMA phase's own walk over the blocks (it runs a chunk behind the loads)
+        e('s_mov_b32 s%d, s%d', S_MB_COL, S_PART(2)[0])
+        e('s_mov_b32 s%d, s%d', S_MB_ROW, S_PART(2)[0])
+        emit_block_flags(e)
     else:
         for i in range(3):
             e('s_mov_b64 s[%d:%d], s[%d:%d]', S_NEXT + 2 * i, S_NEXT + 2 * i + 1, S_PART(i + 1)[0], S_PART(i + 1)[1])
@@ -419,7 +488,7 @@ def inverse_clobbers():
 
 def clobbers():
     v = ['"v%d"' % i for i in list(range(0, V_IN)) + list(range(V_IN + 16, V_LAST + 1))]
-    s = ['"s%d"' % i for i in range(S_DESC, S_NEXT + 6)]
+    s = ['"s%d"' % i for i in range(S_DESC, S_FLAGS + 1)]
     return ', '.join(v + s + ['"vcc"', '"scc"', '"memory"'])
 
 

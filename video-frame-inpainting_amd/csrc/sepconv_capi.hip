@@ -809,7 +809,7 @@ int tai_conv3x3_wino43_forward_blocks(const float* x, int shift_k, const float* 
     const long long tiles = (long long)N * (H / 4) * (W / 4);
     const long long tblocks = (tiles + wino43::TN - 1) / wino43::TN;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    const wino43::Window win{in_h, in_w, in_oy, in_ox, S, ypool ? pool_h : 0, pool_w, pool_oy, pool_ox};
+    const wino43::Window win{in_h, in_w, in_oy, in_ox, S, ypool ? pool_h : 0, pool_w, pool_oy, pool_ox, 3 * S > shift_k ? 1 : 0};
 #define TAI_W43_LAUNCH_BLOCKS(A, E)                                                                                             \
     {                                                                                                                           \
         auto kern = wino43::conv3x3_gen<A, E, 0, true>;                                                                         \
