@@ -53,6 +53,9 @@ def check(asm):
         if get('next_free_vgpr') - get('accum_offset') < 144:
             bad.append('%s: fewer than 144 accumulator registers' % name)
         n = sum(1 for l in lines if 'v_mfma_f32_16x16x4_f32' in l)
+        var = re.match(r'_ZN6wino4311conv3x3_genILin?\d+ELin?\d+ELi(\d+)E', name)
+        if var and var.group(1) != '0':      # <ACT, EPI, VAR != 0>: a timing ablation of the tools build (parts of the loop left out on purpose)
+            continue
         if n != 216:                       # three roles x (the chunk body with the next chunk's loads + the plain one) x 36
             bad.append('%s: %d MFMAs in the chunk loops, expected 216' % (name, n))
     for name, (lines, desc) in kernels(asm, '_ZN6wino437conv3x3I').items():

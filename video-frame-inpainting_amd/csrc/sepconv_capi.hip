@@ -279,7 +279,7 @@ int launch_grad_vh_tiled(const float* gO, const float* in, const float* v, const
 
 extern "C" {
 
-int tai_sepconv_version(void) { return 410; }     // 0.4.1: persistent forward kernel beyond the Infinity Cache: type-A waves at their partners' priority (0.4.0: nt tap loads + reversed walk; source hash)
+int tai_sepconv_version(void) { return 500; }     // 0.5.0: F(4x4, 3x3) chunk loop as generated assembly, displaced-read blocks, any C; (0.4.1: persistent forward kernel beyond the Infinity Cache: type-A waves at their partners' priority (0.4.0: nt tap loads + reversed walk; source hash))
 
 const char* tai_sepconv_last_error(void) { return g_err; }
 
