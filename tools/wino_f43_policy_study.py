@@ -13,6 +13,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
+sys.path.insert(0, os.path.join(ROOT, 'tools', 'experiments', 'probes'))      # wino_f43_study, split_bf16_study (rounds 4's CPU studies)
 import torch
 
 import split_bf16_study as sbs
