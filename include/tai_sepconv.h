@@ -271,6 +271,10 @@ int tai_conv3x3_wino43_forward_parts(const float* const* xs, int nparts, const f
  * argument. */
 int tai_conv3x3_wino_set_arithmetic(int mode);
 int tai_conv3x3_wino_get_arithmetic(void);
+/* The library records which buffers tai_conv3x3_wino_transform_weights filled with a split-bf16 image (the forward entry points follow the
+ * buffer they are handed).  Call this when such a buffer is freed, so that its address can never be read in a layout it no longer has
+ * (returns 1 if a record was dropped, 0 if there was none). */
+int tai_conv3x3_wino_forget_weights(const float* U);
 /* Benchmarking: 0 keeps every layer on the 64-channel x 64-tile workgroup shape; 1 (default) lets layers whose K is a
  * multiple of 128 use the 128 x 32 shape.  Returns the previous value. */
 int tai_conv3x3_wino_set_tall(int on);

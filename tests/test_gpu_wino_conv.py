@@ -76,7 +76,7 @@ def test_conv_bias_act_routes_to_wino_and_tracks_weight_updates():
     x = torch.randn(16, 64, 64, 64, device='cuda')
     with torch.no_grad():
         y1 = conv_ops.conv_bias_act(x, conv.weight, conv.bias, 1, 'relu')
-        assert ('wino', False) in conv.weight._tai_derived                      # the MFMA kernel ran, not MIOpen
+        assert ('wino', False, 0) in conv.weight._tai_derived                      # the MFMA kernel ran, not MIOpen
         assert (y1 - torch.relu(conv(x))).abs().max().item() <= 5e-5
         conv.weight.mul_(2.0)                                                     # in-place update -> U is rebuilt
         y2 = conv_ops.conv_bias_act(x, conv.weight, conv.bias, 1, 'relu')
@@ -89,7 +89,7 @@ def test_transposed_conv_through_wino():
     x = torch.randn(16, 128, 64, 64, device='cuda')
     with torch.no_grad():
         got = conv_ops.conv_bias_act(x, layer.weight, layer.bias, 1, 'relu', transposed=True)
-        assert ('wino', True) in layer.weight._tai_derived
+        assert ('wino', True, 0) in layer.weight._tai_derived
         ref = torch.relu(layer(x))
     assert (got - ref).abs().max().item() <= 5e-5
 
@@ -116,7 +116,7 @@ def test_wino_reads_channel_parts_without_a_cat(nparts):
     conv = torch.nn.Conv2d(64 * nparts, 128, 3, padding=1).cuda()
     with torch.no_grad():
         got = conv_ops.conv_bias_act(tuple(parts), conv.weight, conv.bias, 1, 'relu')
-        assert ('wino', False) in conv.weight._tai_derived
+        assert ('wino', False, 0) in conv.weight._tai_derived
         whole = conv_ops.conv_bias_act(torch.cat(parts, dim=1), conv.weight, conv.bias, 1, 'relu')
     assert torch.equal(got, whole)                      # same kernel, same arithmetic, same order
 
@@ -177,7 +177,7 @@ def test_5x5_and_7x7_through_the_winograd_kernel(k, shape, pool):
             assert torch.equal(yp, F.max_pool2d(y, 2))
         else:
             y = conv_ops.conv_bias_act(x, conv.weight, conv.bias, k // 2, 'relu')
-        assert ('wino_kxk', False) in conv.weight._tai_derived                    # not the MIOpen path
+        assert ('wino_kxk', False, 0) in conv.weight._tai_derived                    # not the MIOpen path
         ref = torch.relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=k // 2))
         mag = F.conv2d(x.double().abs(), conv.weight.double().abs(), conv.bias.double().abs(), padding=k // 2)
     err = ((y.double() - ref).abs() / (1 + mag)).max().item()
@@ -463,8 +463,8 @@ def test_5x5_and_7x7_training_form_gradients_match_autograd_of_conv2d(k, shape, 
     y = conv_ops.conv_bias_act(x, w, b, k // 2, act)
     assert type(y.grad_fn).__name__ == '_WinoConvKxKBackward'
     gx, gw, gb = torch.autograd.grad(y, (x, w, b), go)
-    assert (('wino43_kxk', True) if tile == 4 else ('wino_kxk', True)) in w._tai_derived
-    assert (('wino43_kxk', False) if tile == 4 else ('wino_kxk', False)) in w._tai_derived
+    assert (('wino43_kxk', True) if tile == 4 else ('wino_kxk', True, 0)) in w._tai_derived
+    assert (('wino43_kxk', False) if tile == 4 else ('wino_kxk', False, 0)) in w._tai_derived
     xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
     yd = F.conv2d(xd, wd, bd, padding=k // 2)
     # the ReLU's mask is taken from the fp32 output: a pre-activation within rounding of zero (there are a few among the

@@ -222,3 +222,29 @@ def test_split_kernel_is_bit_reproducible(shape, split_mode):
         _native.check(L.tai_conv3x3_wino_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), N, C, K, H, W, 1, s), 'forward')
         bad += int(not torch.equal(y, first))
     assert bad == 0, bad
+
+
+def test_arithmetics_are_cached_side_by_side_and_registry_entries_die_with_their_buffers():
+    """a switch of the arithmetic used to drop the other arithmetic's transformed weights (a captured graph would then have read
+    freed memory), and the library's record of split-layout buffers grew without bound."""
+    import gc
+    from video_frame_inpainting_amd import _native, conv_ops
+    L = _native.lib()
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1).cuda()
+    x = torch.randn(8, 64, 64, 64, device='cuda')
+    with torch.no_grad():
+        conv_ops.conv_bias_act(x, conv.weight, conv.bias, 1, 'relu')
+        u_fp32 = conv.weight._tai_derived[('wino', False, 0)][1]
+        prev = conv_ops.set_winograd_arithmetic('bf16x3')
+        try:
+            conv_ops.conv_bias_act(x, conv.weight, conv.bias, 1, 'relu')
+            u_split = conv.weight._tai_derived[('wino', False, 1)][1]
+            assert conv.weight._tai_derived[('wino', False, 0)][1] is u_fp32          # still alive next to the split image
+            assert u_split.numel() > u_fp32.numel()
+        finally:
+            conv_ops.set_winograd_arithmetic(prev)
+    ptr = u_split.data_ptr()
+    del u_split
+    conv.weight._tai_derived.clear()
+    gc.collect()
+    assert L.tai_conv3x3_wino_forget_weights(ptr) == 0          # the finalizer already dropped the record

@@ -195,6 +195,8 @@ def lib():
     L.tai_conv3x3_wino_set_arithmetic.argtypes = [I]
     L.tai_conv3x3_wino_set_arithmetic.restype = I
     L.tai_conv3x3_wino_get_arithmetic.argtypes = []
+    L.tai_conv3x3_wino_forget_weights.argtypes = [P]
+    L.tai_conv3x3_wino_forget_weights.restype = I
     L.tai_conv3x3_wino_get_arithmetic.restype = I
     L.tai_conv3x3_wino_set_tall.restype = I
     L.tai_conv3x3_wino_forward_parts.argtypes = [P, I, P, P, P, I, I, I, I, I, I, V]

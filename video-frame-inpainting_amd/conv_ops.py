@@ -44,20 +44,21 @@ def invalidate_derived(module=None):
 
 
 WINOGRAD_ARITHMETICS = {'fp32': 0, 'bf16x3': 1}
+_WINO_ARITH = [0]          # mirrors the library's mode: part of the cache tag of every F(2x2, 3x3) transformed-weight buffer
 
 
 def set_winograd_arithmetic(name):
     """Arithmetic of the Winograd 3x3 GEMMs (``tai_conv3x3_wino_set_arithmetic``): ``'fp32'`` (default: the fp32 MFMA, the
     reference's arithmetic class and the one every parity statement is made on) or ``'bf16x3'`` (opt-in: every fp32 operand
-    as three bf16 terms, six bf16 products per product, fp32 accumulation -- csrc/wino_split.hip.inc).  Cached transformed
-    weights are rebuilt in the new layout; a hipGraph captured before the switch keeps replaying the arithmetic it was
-    captured with.  Returns the previous name."""
+    as three bf16 terms, six bf16 products per product, fp32 accumulation -- csrc/wino_split.hip.inc).  The transformed
+    weights of the two arithmetics are cached side by side (the arithmetic is part of the cache tag), so a hipGraph captured
+    before a switch keeps replaying the arithmetic it was captured with ON BUFFERS THAT STAY ALIVE (the switch used
+    to drop the other arithmetic's buffers, which a captured graph would then have read after free).  Returns the previous name."""
     mode = WINOGRAD_ARITHMETICS[name]
     prev = _native.lib().tai_conv3x3_wino_set_arithmetic(mode)
     if prev < 0:
         raise ValueError(name)
-    if prev != mode:
-        invalidate_derived()
+    _WINO_ARITH[0] = mode
     return [k for k, v in WINOGRAD_ARITHMETICS.items() if v == prev][0]
 
 
@@ -123,18 +124,27 @@ def _cached(weight, tag, make):
     return hit[1]
 
 
+def _registered(U):
+    """A transformed-weight buffer of the F(2x2, 3x3) entry points: the library keeps the addresses of the split-bf16 images it wrote (the
+    forward entry points follow the buffer they are handed); the entry goes when the tensor does (the registry used to grow
+    without bound and a recycled address could be read in the wrong layout)."""
+    import weakref
+    weakref.finalize(U, _native.lib().tai_conv3x3_wino_forget_weights, U.data_ptr())
+    return U
+
+
 def _wino_weights(weight, transposed):
     def make():
         w = _as_conv_weight(weight.detach(), transposed).contiguous()
         K, C = w.shape[0], w.shape[1]
         L = _native.lib()
-        U = torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), dtype=torch.float32, device=w.device)
+        U = _registered(torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), dtype=torch.float32, device=w.device))
         with torch.cuda.device(w.device):
             _native.check(L.tai_conv3x3_wino_transform_weights(w.data_ptr(), U.data_ptr(), K, C,
                                                                torch.cuda.current_stream(w.device).cuda_stream),
                           'tai_conv3x3_wino_transform_weights')
         return U
-    return _cached(weight, ('wino', transposed), make)
+    return _cached(weight, ('wino', transposed, _WINO_ARITH[0]), make)
 
 
 def _wino43_weights(weight, transposed):
@@ -168,13 +178,13 @@ def _wino_weights_kxk(weight, transposed=False):
         w = _block3x3_weight(w.transpose(0, 1).flip(2, 3).contiguous() if transposed else w)
         K, C = w.shape[0], w.shape[1]
         L = _native.lib()
-        U = torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), dtype=torch.float32, device=w.device)
+        U = _registered(torch.empty(L.tai_conv3x3_wino_weight_floats(K, C), dtype=torch.float32, device=w.device))
         with torch.cuda.device(w.device):
             _native.check(L.tai_conv3x3_wino_transform_weights(w.data_ptr(), U.data_ptr(), K, C,
                                                                torch.cuda.current_stream(w.device).cuda_stream),
                           'tai_conv3x3_wino_transform_weights')
         return U
-    return _cached(weight, ('wino_kxk', transposed), make)
+    return _cached(weight, ('wino_kxk', transposed, _WINO_ARITH[0]), make)
 
 
 def _wino43_weights_kxk(weight, transposed=False):
@@ -641,11 +651,13 @@ def _wino_weights_input_grad_part(weight, transposed, i, nparts, tile=2):
         L = _native.lib()
         pre = 'tai_conv3x3_wino43' if tile == 4 else 'tai_conv3x3_wino'
         U = torch.empty(getattr(L, pre + '_weight_floats')(K, C), dtype=torch.float32, device=w.device)
+        if tile == 2:
+            _registered(U)
         with torch.cuda.device(w.device):
             _native.check(getattr(L, pre + '_transform_weights')(w.data_ptr(), U.data_ptr(), K, C, torch.cuda.current_stream(w.device).cuda_stream),
                           pre + '_transform_weights')
         return U
-    return _cached(weight, ('wino_input_grad_part', transposed, i, nparts, tile), make)
+    return _cached(weight, ('wino_input_grad_part', transposed, i, nparts, tile, _WINO_ARITH[0]), make)
 
 
 class _WinoConvKxK(torch.autograd.Function):

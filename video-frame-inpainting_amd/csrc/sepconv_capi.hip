@@ -632,6 +632,11 @@ int tai_conv3x3_wino_set_arithmetic(int mode) {
     return g_wino_arith.exchange(mode, std::memory_order_relaxed);
 }
 int tai_conv3x3_wino_get_arithmetic(void) { return g_wino_arith.load(std::memory_order_relaxed); }
+// the caller is about to free (or has freed) a buffer that tai_conv3x3_wino_transform_weights wrote: drop its layout record
+int tai_conv3x3_wino_forget_weights(const float* U) {
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    return (int)g_split_bufs.erase(U);
+}
 
 long long tai_conv3x3_wino_weight_floats(int K, int C) {
     if (K <= 0 || C <= 0) return 0;
