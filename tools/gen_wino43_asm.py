@@ -69,7 +69,13 @@ S_MB_LEFT, S_MB_COL, S_MB_ROW, S_FLAGS = 84, 85, 86, 87     # displaced-read for
 
 NEG5 = '0xc0a00000'
 BLOCKS = [False]       # generate the displaced-read form (k x k filters as S x S blocks of 3 x 3 taps: see emit_patch_advance)
-ABLATE = set()         # timing experiments of the tools build only (results are then wrong): see ABLATIONS below
+SCHEDULE = {'xform_first', 'vmem_front'}   # the shipped schedule: the patch waves transform the next chunk FIRST (their SIMD partner has the
+                       # matrix pipe to itself meanwhile; both then run MFMAs to the barrier together) and the next chunk's loads / DMA go out
+                       # in front of the MFMA groups.  Same process, x(64,256,32,32)->256 / x(64,512,16,16)->1024 / x(64,128,64,64)->128
+                       # (tools/w43_ablate.py sched, profiles/r05_wino43_schedules.txt): transform first + in front 190.9 / 371.8 / 202.2 us,
+                       # transform first + behind the groups 189.8 / 380.7 / 200.2, transform between groups 3 and 4 + in front 204.7 / 419.8 / 211.7,
+                       # + behind 214.0 / 439.2 / 221.3
+ABLATE = set(SCHEDULE)  # + timing experiments of the tools build only (results are then wrong): see ABLATIONS below
 
 
 def position(i, j):
@@ -111,46 +117,53 @@ def position_ij(p):
 SKIP_N = [0]
 
 
-def emit_mfma_phase(e, extra=None):
+def emit_mfma_phase(e, extra=None, mid=None, mid_lds_ops=0):
     """36 MFMAs on the current stage.  The operands of groups 0 and 1 were requested just before (buffers 0, 1; nothing else on lgkmcnt
-    behind them); group g + 2 is requested while group g runs.  `extra(g)` emits what the role interleaves in front of group g's MFMAs
-    (vector-memory instructions of the next chunk: issued all at once behind the barrier they queue at the CU's one address unit and
-    block the wave's MFMAs behind them).
+    behind them); group g + 2 is requested while group g runs.  `extra(g)` emits what the role issues BEHIND group g's MFMAs (vector-memory
+    instructions of the next chunk: their issue then runs in the shadow of the four MFMAs just queued; issued all at once behind the
+    barrier they queue at the CU's one address unit and block the wave's MFMAs behind them).  `mid()` is emitted between groups 3 and 4
+    (the patch waves' transform of the next chunk: after the barrier BOTH waves of a SIMD start with MFMAs); it issues `mid_lds_ops` LDS
+    writes, which the counted waits of groups 4 and 5 step over.
     Displaced-read form: a k x k filter cut into 3 x 3 blocks is zero past k, so in the LAST block row (column) the third tap row (column)
     is all zeros and with it, exactly, row (column) 5 of that block's 6 x 6 transformed weights (G's last row picks the third tap): those
     MFMAs multiply by zeros and are skipped -- s87 bit 0: last block row (positions (5, j)), bit 1: last block column (positions (i, 5)) --
     by forward branches that fall through when nothing is skipped.  Within a group the always-issued MFMAs go first; every accumulator
     keeps its own summation order, so the results do not change."""
     for g in range(9):
+        if g == 4 and mid:
+            mid()
         if g < 7:
             emit_read(e, g + 2, (g + 2) % 3)
-        if extra:
+        if extra and 'vmem_front' in ABLATE:
             extra(g)
-        e('s_waitcnt lgkmcnt(%d)', 4 if g < 7 else (2 if g == 7 else 0))
+        # LDS operations issued behind R(g), which may stay in flight: R(g + 1), R(g + 2) and, for groups 4 and 5, the mid block's writes
+        behind = (4 if g < 7 else (2 if g == 7 else 0)) + (mid_lds_ops if (mid and g in (4, 5)) else 0)
+        e('s_waitcnt lgkmcnt(%d)', behind)
         buf = g % 3
-        if 'nomfma' in ABLATE:
-            continue
-        kinds = {}
-        for j in range(4):
-            i5, j5 = position_ij(4 * g + j)
-            kinds.setdefault((i5 == 5, j5 == 5) if BLOCKS[0] else (False, False), []).append(j)
-        for kind in ((False, False), (True, False), (False, True), (True, True)):
-            if kind not in kinds:
-                continue
-            label = None
-            if kind != (False, False):
-                SKIP_N[0] += 1
-                label = 'SKIP%d' % SKIP_N[0]
-                if kind == (True, True):
-                    e('s_cmp_lg_u32 s%d, 0', S_FLAGS)
-                else:
-                    e('s_bitcmp1_b32 s%d, %d', S_FLAGS, 0 if kind[0] else 1)
-                e('s_cbranch_scc1 %s', e.ref(label))
-            for j in kinds[kind]:
-                p = 4 * g + j
-                e('v_mfma_f32_16x16x4_f32 a[%d:%d], v%d, v%d, a[%d:%d]', 4 * p, 4 * p + 3, A_BUF[buf] + j, B_BUF[buf] + j, 4 * p, 4 * p + 3)
-            if label:
-                e.label(label)
+        if 'nomfma' not in ABLATE:
+            kinds = {}
+            for j in range(4):
+                i5, j5 = position_ij(4 * g + j)
+                kinds.setdefault((i5 == 5, j5 == 5) if BLOCKS[0] else (False, False), []).append(j)
+            for kind in ((False, False), (True, False), (False, True), (True, True)):
+                if kind not in kinds:
+                    continue
+                label = None
+                if kind != (False, False):
+                    SKIP_N[0] += 1
+                    label = 'SKIP%d' % SKIP_N[0]
+                    if kind == (True, True):
+                        e('s_cmp_lg_u32 s%d, 0', S_FLAGS)
+                    else:
+                        e('s_bitcmp1_b32 s%d, %d', S_FLAGS, 0 if kind[0] else 1)
+                    e('s_cbranch_scc1 %s', e.ref(label))
+                for j in kinds[kind]:
+                    p = 4 * g + j
+                    e('v_mfma_f32_16x16x4_f32 a[%d:%d], v%d, v%d, a[%d:%d]', 4 * p, 4 * p + 3, A_BUF[buf] + j, B_BUF[buf] + j, 4 * p, 4 * p + 3)
+                if label:
+                    e.label(label)
+        if extra and 'vmem_front' not in ABLATE:
+            extra(g)
 
 
 def emit_block_flags_advance(e, tag):
@@ -339,34 +352,53 @@ def emit_role(e, role):
         emit_dma_first(e)
         e('s_waitcnt vmcnt(0)')
     e('s_barrier')
-    # ---- chunk loop.  Two bodies per role: with a next chunk (its loads / DMA interleaved with the MFMA groups) and the last chunk.
+    # ---- chunk loop.  Bodies per role: with a next chunk (its transform in the middle of the MFMA groups, its loads / DMA behind them)
+    # and the plain one.  Behind the barrier every wave starts with MFMAs.
     e.label('LOOP_' + tag)
+    if not (patch and 'xform_first' in ABLATE):
+        emit_read(e, 0, 0)
+        emit_read(e, 1, 1)
     if patch:
+        def transform_next():
+            e('s_waitcnt vmcnt(0)')                       # the next chunk's patch rows (requested during the previous chunk)
+            emit_transform(e, role)                       # ... transformed into the other stage (6 LDS writes)
         e('s_cmp_lt_u32 s%d, 2', S_REM)                  # a next chunk?
         e('s_cbranch_scc1 %s', e.ref('PLAIN_' + tag))
-        e('s_waitcnt vmcnt(0)')                           # its patch rows (requested during the previous chunk)
-        emit_transform(e, role)                           # ... transformed into the other stage
-        emit_read(e, 0, 0)
-        emit_read(e, 1, 1)
-        e('s_cmp_lt_u32 s%d, 3', S_REM)                  # a chunk after that?
-        e('s_cbranch_scc1 %s', e.ref('PLAIN_NOREAD_' + tag))
-        # its 12 loads, one patch row in front of each of the first six MFMA groups
-        emit_mfma_phase(e, lambda g: emit_patch_row_load(e, g) if g < 6 else None)
-        emit_patch_advance(e, tag + 'L')
-        e('s_branch %s', e.ref('CHUNK_END_' + tag))
+        if 'xform_first' in ABLATE:
+            # the transform in front of the MFMA groups (its six LDS writes sit behind the requests of groups 0 and 1: the counted wait of
+            # group 0 -- everything but the two youngest requests -- covers them)
+            transform_next()
+            emit_read(e, 0, 0)
+            emit_read(e, 1, 1)
+            e('s_cmp_lt_u32 s%d, 3', S_REM)
+            e('s_cbranch_scc1 %s', e.ref('PLAIN_NOREAD_' + tag))
+            emit_mfma_phase(e, lambda g: emit_patch_row_load(e, g) if g < 6 else None)
+            emit_patch_advance(e, tag + 'L')
+            e('s_branch %s', e.ref('CHUNK_END_' + tag))
+        else:
+            e('s_cmp_lt_u32 s%d, 3', S_REM)                  # a chunk after that?
+            e('s_cbranch_scc1 %s', e.ref('NOLOADS_' + tag))
+            # the loads of the chunk after the next, one patch row behind each of groups 4 to 8 and the last behind group 8 as well: the
+            # patch registers are free once the transform has read them
+            rows = {4: (0,), 5: (1,), 6: (2,), 7: (3,), 8: (4, 5)}
+            emit_mfma_phase(e, lambda g: [emit_patch_row_load(e, r) for r in rows.get(g, ())], transform_next, 6)
+            emit_patch_advance(e, tag + 'L')
+            e('s_branch %s', e.ref('CHUNK_END_' + tag))
+            e.label('NOLOADS_' + tag)
+            emit_mfma_phase(e, None, transform_next, 6)
+            e('s_branch %s', e.ref('CHUNK_END_' + tag))
         e.label('PLAIN_' + tag)
-        emit_read(e, 0, 0)
-        emit_read(e, 1, 1)
-        e.label('PLAIN_NOREAD_' + tag)
+        if 'xform_first' in ABLATE:
+            emit_read(e, 0, 0)
+            emit_read(e, 1, 1)
+            e.label('PLAIN_NOREAD_' + tag)
         emit_mfma_phase(e)
         e.label('CHUNK_END_' + tag)
         e('s_waitcnt lgkmcnt(0)')
     else:
-        emit_read(e, 0, 0)
-        emit_read(e, 1, 1)
         e('s_cmp_lt_u32 s%d, 2', S_REM)
         e('s_cbranch_scc1 %s', e.ref('PLAIN_' + tag))
-        # the nine DMAs of the next chunk's weights in front of the first six groups (2, 1, 2, 1, 2, 1): the last one has three groups to land in
+        # the nine DMAs of the next chunk's weights behind the first six groups (2, 1, 2, 1, 2, 1): the last one has three groups to land in
         pieces = {0: (0, 1), 1: (2,), 2: (3, 4), 3: (5,), 4: (6, 7), 5: (8,)}
         emit_mfma_phase(e, lambda g: [emit_dma_piece(e, r) for r in pieces.get(g, ())])
         e('s_branch %s', e.ref('CHUNK_END_' + tag))
@@ -398,7 +430,7 @@ def emit_dma_first(e):
 
 ABLATIONS = {1: {'noxform'}, 2: {'noloads'}, 3: {'nodma'}, 4: {'nobarrier'}, 5: {'nomfma'}, 6: {'noxform', 'noloads', 'nodma'},
              7: {'noxform', 'noloads', 'nodma', 'nobarrier'}, 8: {'noxform', 'noloads', 'nodma', 'nobarrier', 'noreads'},
-             9: {'noxform', 'noloads'}}
+             9: {'noxform', 'noloads'}, 10: {'-xform_first', '-vmem_front'}, 11: {'-vmem_front'}, 12: {'-xform_first'}}
 
 
 def generate():
@@ -515,13 +547,14 @@ def main():
     text.append('#ifdef TAI_TIMING_VARIANTS   // timing experiments (wrong results by design): tools build only')
     for v, flags in sorted(ABLATIONS.items()):
         ABLATE.clear()
-        ABLATE.update(flags)
+        ABLATE.update((SCHEDULE | flags) - set(f[1:] for f in flags if f.startswith('-')))
         text.append('// V%d: %s' % (v, ' '.join(sorted(flags))))
         text.append('#define TAI_W43_LOOP_ASM_V%d \\' % v)
         for l in generate():
             text.append('    "%s\\n" \\' % l)
         text.append('    ""')
     ABLATE.clear()
+    ABLATE.update(SCHEDULE)
     text.append('#endif')
     for r in range(4):
         text.append('#define TAI_W43_INVERSE_ASM_R%d \\' % r)

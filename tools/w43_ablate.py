@@ -20,7 +20,11 @@ _native.check(L.tai_conv3x3_wino43_transform_weights(w.data_ptr(), U.data_ptr(),
 y = torch.empty((N, K, H, W), device='cuda')
 names = {0: 'full kernel', 101: 'without the patch transform arithmetic', 102: 'without the patch loads', 103: 'without the weight DMA',
          104: 'without the barrier', 105: 'without the MFMAs', 106: 'without transform, patch loads and DMA', 107: '... and without the barrier',
-         108: '... and without the operand reads (MFMAs alone)', 109: 'without transform and patch loads'}
+         108: '... and without the operand reads (MFMAs alone)', 109: 'without transform and patch loads',
+         110: 'SCHEDULE transform in the middle, loads / DMA behind the groups', 111: 'SCHEDULE transform first, loads / DMA behind the groups',
+         112: 'SCHEDULE transform in the middle, loads / DMA in front'}      # (the full kernel: transform first, loads / DMA in front)
+if len(sys.argv) > 2:
+    names = {k: v for k, v in names.items() if k in (0, 110, 111, 112)}
 
 
 def timed(form, n=20):

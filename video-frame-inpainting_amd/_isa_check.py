@@ -56,7 +56,7 @@ def check(asm):
         var = re.match(r'_ZN6wino4311conv3x3_genILin?\d+ELin?\d+ELi(\d+)E', name)
         if var and var.group(1) != '0':      # <ACT, EPI, VAR != 0>: a timing ablation of the tools build (parts of the loop left out on purpose)
             continue
-        if n != 216:                       # three roles x (the chunk body with the next chunk's loads + the plain one) x 36
+        if n != 216:                       # chunk bodies of 36 MFMAs: per role one with the next chunk's loads / DMA and the plain one
             bad.append('%s: %d MFMAs in the chunk loops, expected 216' % (name, n))
     for name, (lines, desc) in kernels(asm, '_ZN6wino437conv3x3I').items():
         pending, in_asm = {}, False

@@ -690,7 +690,7 @@ int tai_conv3x3_wino43_transform_weights(const float* weight, float* U, int K, i
 static std::atomic<int> g_wino43_waves{0};
 int tai_conv3x3_wino43_set_waves(int waves) {
 #ifdef TAI_TIMING_VARIANTS   // 101..109: ablations of the generated loop (timing only, wrong results; tools/gen_wino43_asm.py ABLATIONS)
-    if (waves >= 101 && waves <= 109) return g_wino43_waves.exchange(waves, std::memory_order_relaxed);
+    if (waves >= 101 && waves <= 112) return g_wino43_waves.exchange(waves, std::memory_order_relaxed);
 #endif
     if (waves != 0 && waves != 4 && waves != 8) return -1;
     return g_wino43_waves.exchange(waves, std::memory_order_relaxed);
@@ -747,7 +747,7 @@ static int wino43_forward_impl(const float* const* xs, int nparts, const float* 
     switch (g_wino43_waves.load(std::memory_order_relaxed)) {
         case 101: TAI_W43_LAUNCH_VAR(1) case 102: TAI_W43_LAUNCH_VAR(2) case 103: TAI_W43_LAUNCH_VAR(3) case 104: TAI_W43_LAUNCH_VAR(4)
         case 105: TAI_W43_LAUNCH_VAR(5) case 106: TAI_W43_LAUNCH_VAR(6) case 107: TAI_W43_LAUNCH_VAR(7) case 108: TAI_W43_LAUNCH_VAR(8)
-        case 109: TAI_W43_LAUNCH_VAR(9)
+        case 109: TAI_W43_LAUNCH_VAR(9) case 110: TAI_W43_LAUNCH_VAR(10) case 111: TAI_W43_LAUNCH_VAR(11) case 112: TAI_W43_LAUNCH_VAR(12)
         default: break;
     }
 #undef TAI_W43_LAUNCH_VAR
