@@ -17,8 +17,17 @@ def test_tile_switch_and_layer_selection():
         assert not conv_ops._wino43_ok(64, 64, 256, 32, 32)              # C < 128
         assert not conv_ops._wino43_ok(64, 256, 64, 32, 32)              # K < 128
         assert not conv_ops._wino43_ok(64, 256, 256, 30, 32)             # H % 4
-        assert not conv_ops._wino43_ok(64, 512, 256, 16, 16, nparts=2)   # 32 x 4 = 128 workgroups: too few
-        assert not conv_ops._wino43_ok(160, 256, 256, 16, 16)            # 80 x 4 = 320
+        assert not conv_ops._wino43_ok(64, 512, 256, 16, 16, nparts=2)   # 32 x 4 = 128 workgroups: too few (the threshold is 150)
+        assert conv_ops._wino43_ok(160, 256, 256, 16, 16)                # 80 x 4 = 320 (round 4's threshold of 400 refused it)
+        # a layer outside MC-Net's recurrence (kernel network, merge residuals) takes the 4 x 4 tile at any width, any channel count
+        import torch
+        narrow = torch.nn.Conv2d(51, 51, 3, padding=1)
+        assert not conv_ops._wino43_ok(160, 51, 51, 128, 128, 1, narrow.weight)
+        conv_ops.mark_outside_recurrence(narrow)
+        assert conv_ops._wino43_ok(160, 51, 51, 128, 128, 1, narrow.weight)
+        assert not conv_ops._wino43_ok(160, 8, 51, 128, 128, 1, narrow.weight)          # fewer than 16 input channels: not worth a chunk loop
+        assert not conv_ops._wino43_ok(160, 102, 51, 128, 128, 2, narrow.weight)        # parts whose channel count is no multiple of 4
+        assert conv_ops._wino43_blocks_ok(64, 128, 256, 32, 32) and not conv_ops._wino43_blocks_ok(2, 128, 256, 32, 32)
         assert not conv_ops._wino43_ok(64, 384, 256, 32, 32, nparts=4) or (384 // 4) % 4 == 0
         assert not conv_ops._wino43_ok(4096, 1024, 1024, 32, 32)         # 2^32 elements: beyond the kernel's 32-bit offsets
     finally:
