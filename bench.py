@@ -265,7 +265,7 @@ def conv_roofline(device):
             w = (torch.randn(K, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).to(device)
             b = torch.zeros(K, device=device)
             y = torch.empty(N, K, H, W, device=device)
-            # the kernel conv_ops dispatches this layer to: F(4x4, 3x3) on the wide layers (C, K >= 128), on the layers outside MC-Net's
+            # the kernel conv_ops dispatches this layer to: F(4x4, 3x3) on the layers with C, K >= 64, on the layers outside MC-Net's
             # recurrence and on MotionEnc's blocks -- each with enough workgroups -- else F(2x2, 3x3)
             if kind == 'any':
                 w._tai_f43_any_width = True
@@ -860,7 +860,7 @@ def main():
                    'clips_per_gpu': B, 'global_clips': world * B, 'parallelism': 'clip-sharded x%d, no collective' % world,
                    'ranks': world, 'backend': ('rccl (torch.distributed "nccl")' if backend == 'nccl' else backend),
                    'weights': 'seeded N(0, 1/fan_in) weights and N(0, 0.01) biases (synthetic.seeded_init, seed %d)' % WEIGHT_SEED,
-                   'convolutions': 'fp32 on the fp32 MFMA: Winograd F(4x4,3x3) on the 3x3 layers with C >= 128 and K >= 128, on every layer of the '
+                   'convolutions': 'fp32 on the fp32 MFMA: Winograd F(4x4,3x3), interpolation points (0, +-3/4, +-3/2, inf), on the 3x3 layers with C >= 64 and K >= 64, on every layer of the '
                                    'kernel network and the merge residuals and on the 5x5 / 7x7 MotionEnc layers as 3x3 blocks (each with '
                                    '>= %d workgroups), F(2x2,3x3) on the others (conv_ops.set_winograd_tile)' % conv_ops_threshold()},
     }

@@ -250,11 +250,9 @@ int tai_conv3x3_wino43_forward_ex(const float* const* xs, int nparts, const floa
 int tai_conv3x3_wino43_forward_blocks(const float* x, int shift_k, const float* U, const float* bias, float* y, float* ypool, int pool_h,
                                       int pool_w, int pool_oy, int pool_ox, int N, int C, int K, int H, int W, int in_h, int in_w, int in_oy,
                                       int in_ox, int act, void* hip_stream);
-/* Form of that kernel, process-wide: 0 (default since round 5): eight waves with the whole channel-chunk loop as one generated asm
- * statement (csrc/wino43_chunkloop.inc, tools/gen_wino43_asm.py); 8 / 4: round 4's compiler-scheduled forms with eight waves (two per
- * SIMD, 16 channels x 16 tiles each) or four (one per SIMD, 32 x 16 each), kept for A/B: the same bits as each other; the generated
- * form shares the +- pairs of B^T in the patch transform, so it differs from them by rounding.
- * Returns the previous value, -1 on a bad one. */
+/* Kept for the tools build: 0 = the kernel; values 101-112 select timing ablations / schedule variants of its generated chunk loop where the
+ * library was built with -DTAI_TIMING_VARIANTS (wrong results by design).  Returns the previous value, -1 on a value this build does not have
+ * (round 4's compiler-scheduled forms 8 / 4 are no longer in the library). */
 int tai_conv3x3_wino43_set_waves(int waves);
 /* ... with the input given as 1 to 4 equal channel parts (contiguous [N, C / nparts, H, W] tensors; C / nparts a multiple of 4): the
  * operands of a torch.cat along the channels that is never materialised (tai_conv3x3_wino_forward_parts' counterpart). */

@@ -11,9 +11,9 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 _ACT = {None: 0, 'relu': 1, 'tanh': 2}
-# F(4x4, 3x3) in fp32: the transforms multiply by up to 8 (A^T), 5 (B^T) and 1/24 (G) before and after the products; against the
-# magnitude sum of a dot product its error is ~10x F(2x2, 3x3)'s (bound there: 4e-6, tests/test_gpu_wino_conv.py)
-TOL = 6e-5
+# F(4x4, 3x3) in fp32 on the points (0, +-3/4, +-3/2, inf): against the magnitude sum of a dot product its error is ~3-4x F(2x2, 3x3)'s
+# (bound there: 4e-6, tests/test_gpu_wino_conv.py; with Lavin's points 0, +-1, +-2, inf it was ~15x and this bound 6e-5)
+TOL = 2e-5
 
 
 def _run(x_parts, w, b, act):
@@ -155,46 +155,28 @@ def test_wino43_rejects_what_it_cannot_run():
     s = torch.cuda.current_stream().cuda_stream
     assert L.tai_conv3x3_wino43_weight_floats(64, 6) == 36 * 64 * 8                                           # C padded to a multiple of 4
     assert L.tai_conv3x3_wino43_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 8, 64, 6, 8, 0, s) != 0      # H % 4
-    prev = L.tai_conv3x3_wino43_set_waves(8)            # C % 4: the generated form only
-    assert L.tai_conv3x3_wino43_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 6, 64, 8, 8, 0, s) != 0
-    L.tai_conv3x3_wino43_set_waves(prev)
     xs2 = (ctypes.c_void_p * 2)(x.data_ptr(), x.data_ptr())
     assert L.tai_conv3x3_wino43_forward_parts(xs2, 2, U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 12, 64, 8, 8, 0, s) != 0     # parts of 6 channels
     assert L.tai_conv3x3_wino43_forward(x.data_ptr(), U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 8, 64, 8, 8, 3, s) != 0      # act
     assert L.tai_conv3x3_wino43_forward(None, U.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 8, 64, 8, 8, 0, s) != 0
 
 
-def test_wino43_is_bit_reproducible_and_both_workgroup_forms_give_the_same_bits():
+def test_wino43_is_bit_reproducible():
     from video_frame_inpainting_amd import _native
     L = _native.lib()
     x, w, b = _operands(8, 256, 256, 32, 32)
     first = _run([x], w, b, 'relu').clone()
     for _ in range(20):
         assert torch.equal(_run([x], w, b, 'relu'), first)
-    assert L.tai_conv3x3_wino43_set_waves(3) == -1
-    # round 4's compiler-scheduled forms: one wave per SIMD (32 channels x 16 tiles per wave) and two; the default (0) is the generated
-    # chunk loop, whose patch transform shares the +- pairs of B^T: equal to them up to rounding, checked against fp64 above
-    prev = L.tai_conv3x3_wino43_set_waves(4)
-    try:
-        assert prev == 0
-        for shape in ((8, 256, 256, 32, 32), (2, 8, 70, 12, 12), (3, 128, 128, 8, 20)):
-            x, w, b = _operands(*shape)
-            four = _run([x], w, b, 'tanh').clone()
-            L.tai_conv3x3_wino43_set_waves(8)
-            assert torch.equal(_run([x], w, b, 'tanh'), four)
-            L.tai_conv3x3_wino43_set_waves(0)
-            gen = _run([x], w, b, 'tanh')
-            assert float((gen - four).abs().max()) <= 2e-5 * float(four.abs().max())
-            L.tai_conv3x3_wino43_set_waves(4)
-    finally:
-        L.tai_conv3x3_wino43_set_waves(prev)
+    assert L.tai_conv3x3_wino43_set_waves(3) == -1 and L.tai_conv3x3_wino43_set_waves(8) == -1      # round 4's forms are gone
+    assert L.tai_conv3x3_wino43_set_waves(0) == 0
 
 
 def test_conv_ops_takes_the_4x4_tile_only_when_asked_and_only_on_wide_layers(monkeypatch):
     from video_frame_inpainting_amd import conv_ops
     monkeypatch.setattr(conv_ops, 'WINO43_MIN_WORKGROUPS', 1)
     x, w, b = _operands(16, 128, 128, 32, 32)          # (conv_ops leaves layers of fewer than 72 F(2x2, 3x3) workgroups to MIOpen)
-    xs, ws, bs = _operands(32, 64, 64, 32, 32)
+    xs, ws, bs = _operands(32, 48, 48, 32, 32)
     with torch.no_grad():
         before = conv_ops.set_winograd_tile(2)
         y2, y2s = conv_ops.conv_bias_act(x, w, b, 1, 'relu'), conv_ops.conv_bias_act(xs, ws, bs, 1, 'relu')
@@ -204,7 +186,7 @@ def test_conv_ops_takes_the_4x4_tile_only_when_asked_and_only_on_wide_layers(mon
             y4, y4s = conv_ops.conv_bias_act(x, w, b, 1, 'relu'), conv_ops.conv_bias_act(xs, ws, bs, 1, 'relu')
             y4p = conv_ops.conv_bias_act((x[:, :64].contiguous(), x[:, 64:].contiguous()), w, b, 1, 'relu')
             # a narrow layer outside MC-Net's recurrence (the kernel network, the merge residuals: conv_ops.mark_outside_recurrence)
-            narrow = torch.nn.Conv2d(64, 64, 3, padding=1).cuda()
+            narrow = torch.nn.Conv2d(48, 48, 3, padding=1).cuda()
             with torch.no_grad():
                 narrow.weight.copy_(ws)
                 narrow.bias.copy_(bs)
@@ -212,7 +194,7 @@ def test_conv_ops_takes_the_4x4_tile_only_when_asked_and_only_on_wide_layers(mon
             y4m = conv_ops.conv_bias_act(xs, narrow.weight, narrow.bias, 1, 'relu')
         finally:
             conv_ops.set_winograd_tile(before)
-    assert torch.equal(y4s, y2s)                                  # C = K = 64: stays on F(2x2, 3x3) ...
+    assert torch.equal(y4s, y2s)                                  # C = K = 48 < WINO43_MIN_CHANNELS: stays on F(2x2, 3x3) ...
     assert not torch.equal(y4m, y2s) and torch.equal(y4m, _run([xs], ws, bs, 'relu'))       # ... unless the layer is marked
     assert not torch.equal(y4, y2) and torch.equal(y4, _run([x], w, b, 'relu')) and torch.equal(y4p, y4)
     assert float((y4 - y2).abs().max()) <= 1e-4 * float(y2.abs().max())

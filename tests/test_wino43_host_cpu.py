@@ -14,8 +14,9 @@ def test_tile_switch_and_layer_selection():
         assert prev == 2 and conv_ops.get_winograd_tile() == 4
         assert conv_ops._wino43_ok(64, 256, 256, 32, 32)                 # 128 tile blocks x 4 channel blocks = 512 workgroups
         assert conv_ops._wino43_ok(64, 512, 1024, 16, 16, nparts=2)      # the ConvLSTM's (input, h)
-        assert not conv_ops._wino43_ok(64, 64, 256, 32, 32)              # C < 128
-        assert not conv_ops._wino43_ok(64, 256, 64, 32, 32)              # K < 128
+        assert conv_ops._wino43_ok(64, 64, 64, 128, 128)                 # MC-Net's first block (WINO43_MIN_CHANNELS = 64 since the points change)
+        assert not conv_ops._wino43_ok(64, 32, 256, 32, 32)              # C < 64
+        assert not conv_ops._wino43_ok(64, 256, 32, 32, 32)              # K < 64
         assert not conv_ops._wino43_ok(64, 256, 256, 30, 32)             # H % 4
         assert not conv_ops._wino43_ok(64, 512, 256, 16, 16, nparts=2)   # 32 x 4 = 128 workgroups: too few (the threshold is 150)
         assert conv_ops._wino43_ok(160, 256, 256, 16, 16)                # 80 x 4 = 320 (round 4's threshold of 400 refused it)

@@ -67,7 +67,25 @@ S_DST_OTHER, S_DST_THIS, S_T = 74, 75, 76
 S_NEXT = 78                               # s[78:83]: bases of parts 1..3, rotated down at every part switch (even: s_mov_b64)
 S_MB_LEFT, S_MB_COL, S_MB_ROW, S_FLAGS = 84, 85, 86, 87     # displaced-read form: the block the MFMA phase is in, and its zero-tap flags
 
-NEG5 = '0xc0a00000'
+# Interpolation points (0, +-A_PT, +-B_PT, inf).  Lavin's (0, +-1, +-2, inf) put constants up to 5 into B^T and 8 into A^T; the same Cook-Toom
+# construction on (0, +-3/4, +-3/2, inf) has the same structure (rows +-a are p +- a q with p = x4 - b^2 x2, q = x3 - b^2 x1; rows +-b the same
+# with a and b exchanged; rows 0 / inf are x4 - (a^2 + b^2) x2 + a^2 b^2 x0) and a quarter of the fp32 rounding error per layer (1.5e-6 against
+# 5.5-8e-6 of the output's maximum at 64 -> 64, F(2x2, 3x3): 3.5e-7; tools/wino_f43_points_study.py --scan, profiles/r05_wino_f43_points_scan.txt);
+# every constant below is a multiple of 1/64: exact in fp32.  wino43::transform_weights (G) and the inverse transform use the same points.
+from fractions import Fraction as _Fr
+import struct as _struct
+A_PT, B_PT = _Fr(3, 4), _Fr(3, 2)
+
+
+def lit(x):
+    """the fp32 bit pattern of a constant, as an instruction literal (each one here is exactly representable)"""
+    f = float(x)
+    bits = _struct.unpack('<I', _struct.pack('<f', f))[0]
+    assert _Fr(_struct.unpack('<f', _struct.pack('<I', bits))[0]) == _Fr(x), x
+    return '0x%08x' % bits
+
+
+C_A2B2, C_NSUM = A_PT ** 2 * B_PT ** 2, -(A_PT ** 2 + B_PT ** 2)       # rows 0 / inf: a^2 b^2 x0 - (a^2 + b^2) x2 + x4
 BLOCKS = [False]       # generate the displaced-read form (k x k filters as S x S blocks of 3 x 3 taps: see emit_patch_advance)
 SCHEDULE = {'xform_first', 'vmem_front'}   # the shipped schedule: the patch waves transform the next chunk FIRST (their SIMD partner has the
                        # matrix pipe to itself meanwhile; both then run MFMAs to the barrier together) and the next chunk's loads / DMA go out
@@ -238,41 +256,41 @@ def emit_patch_loads(e, tag):
 
 
 def bt_rows_half(e, half, x, out, t0, t1):
-    """the three B^T rows of a half applied to six values.  half 0: x = [x0, x1, x2, x3, x4] -> rows 0, 1, 2;
-    half 1: x = [x1, x2, x3, x4, x5] -> rows 3, 4, 5.  out: three destination registers.  6 instructions."""
+    """the three B^T rows of a half applied to six values.  half 0: x = [x0, x1, x2, x3, x4] -> rows 0, +a, -a;
+    half 1: x = [x1, x2, x3, x4, x5] -> rows +b, -b, inf.  out: three destination registers.  6 instructions."""
     if half == 0:
         x0, x1, x2, x3, x4 = x
-        e('v_fmamk_f32 v%d, v%d, %s, v%d', out[0], x2, NEG5, x4)          # x4 - 5 x2
-        e('v_fma_f32 v%d, -4.0, v%d, v%d', t0, x2, x4)                     # p = x4 - 4 x2
-        e('v_fma_f32 v%d, -4.0, v%d, v%d', t1, x1, x3)                     # q = x3 - 4 x1
-        e('v_fmac_f32 v%d, 4.0, v%d', out[0], x0)                          # row 0 = 4 x0 - 5 x2 + x4
-        e('v_add_f32 v%d, v%d, v%d', out[1], t0, t1)                       # row 1 = p + q
-        e('v_sub_f32 v%d, v%d, v%d', out[2], t0, t1)                       # row 2 = p - q
+        e('v_fmamk_f32 v%d, v%d, %s, v%d', out[0], x2, lit(C_NSUM), x4)              # x4 - (a^2 + b^2) x2
+        e('v_fmamk_f32 v%d, v%d, %s, v%d', t0, x2, lit(-B_PT ** 2), x4)              # p = x4 - b^2 x2
+        e('v_fmamk_f32 v%d, v%d, %s, v%d', t1, x1, lit(-B_PT ** 2), x3)              # q = x3 - b^2 x1
+        e('v_fmac_f32 v%d, %s, v%d', out[0], lit(C_A2B2), x0)                        # row 0 = a^2 b^2 x0 - (a^2 + b^2) x2 + x4
+        e('v_fmamk_f32 v%d, v%d, %s, v%d', out[1], t1, lit(A_PT), t0)                # row +a = p + a q
+        e('v_fmamk_f32 v%d, v%d, %s, v%d', out[2], t1, lit(-A_PT), t0)               # row -a = p - a q
     else:
         x1, x2, x3, x4, x5 = x
-        e('v_fmamk_f32 v%d, v%d, %s, v%d', out[2], x3, NEG5, x5)          # x5 - 5 x3
-        e('v_sub_f32 v%d, v%d, v%d', t0, x4, x2)                           # p = x4 - x2
-        e('v_sub_f32 v%d, v%d, v%d', t1, x3, x1)                           # s = x3 - x1
-        e('v_fmac_f32 v%d, 4.0, v%d', out[2], x1)                          # row 5 = 4 x1 - 5 x3 + x5
-        e('v_fma_f32 v%d, 2.0, v%d, v%d', out[0], t1, t0)                  # row 3 = p + 2 s
-        e('v_fma_f32 v%d, -2.0, v%d, v%d', out[1], t1, t0)                 # row 4 = p - 2 s
+        e('v_fmamk_f32 v%d, v%d, %s, v%d', out[2], x3, lit(C_NSUM), x5)              # x5 - (a^2 + b^2) x3
+        e('v_fmamk_f32 v%d, v%d, %s, v%d', t0, x2, lit(-A_PT ** 2), x4)              # p = x4 - a^2 x2
+        e('v_fmamk_f32 v%d, v%d, %s, v%d', t1, x1, lit(-A_PT ** 2), x3)              # q = x3 - a^2 x1
+        e('v_fmac_f32 v%d, %s, v%d', out[2], lit(C_A2B2), x1)                        # row inf = a^2 b^2 x1 - (a^2 + b^2) x3 + x5
+        e('v_fmamk_f32 v%d, v%d, %s, v%d', out[0], t1, lit(B_PT), t0)                # row +b = p + b q
+        e('v_fmamk_f32 v%d, v%d, %s, v%d', out[1], t1, lit(-B_PT), t0)               # row -b = p - b q
 
 
 def bt_rows_all(e, x, out, t):
     """all six B^T rows applied to x[0..5] -> out[0..5]; 12 instructions; t: four temporaries."""
     x0, x1, x2, x3, x4, x5 = x
-    e('v_fmamk_f32 v%d, v%d, %s, v%d', out[0], x2, NEG5, x4)
-    e('v_fmamk_f32 v%d, v%d, %s, v%d', out[5], x3, NEG5, x5)
-    e('v_fma_f32 v%d, -4.0, v%d, v%d', t[0], x2, x4)
-    e('v_fma_f32 v%d, -4.0, v%d, v%d', t[1], x1, x3)
-    e('v_sub_f32 v%d, v%d, v%d', t[2], x4, x2)
-    e('v_sub_f32 v%d, v%d, v%d', t[3], x3, x1)
-    e('v_fmac_f32 v%d, 4.0, v%d', out[0], x0)
-    e('v_fmac_f32 v%d, 4.0, v%d', out[5], x1)
-    e('v_add_f32 v%d, v%d, v%d', out[1], t[0], t[1])
-    e('v_sub_f32 v%d, v%d, v%d', out[2], t[0], t[1])
-    e('v_fma_f32 v%d, 2.0, v%d, v%d', out[3], t[3], t[2])
-    e('v_fma_f32 v%d, -2.0, v%d, v%d', out[4], t[3], t[2])
+    e('v_fmamk_f32 v%d, v%d, %s, v%d', out[0], x2, lit(C_NSUM), x4)
+    e('v_fmamk_f32 v%d, v%d, %s, v%d', out[5], x3, lit(C_NSUM), x5)
+    e('v_fmamk_f32 v%d, v%d, %s, v%d', t[0], x2, lit(-B_PT ** 2), x4)
+    e('v_fmamk_f32 v%d, v%d, %s, v%d', t[1], x1, lit(-B_PT ** 2), x3)
+    e('v_fmamk_f32 v%d, v%d, %s, v%d', t[2], x2, lit(-A_PT ** 2), x4)
+    e('v_fmamk_f32 v%d, v%d, %s, v%d', t[3], x1, lit(-A_PT ** 2), x3)
+    e('v_fmac_f32 v%d, %s, v%d', out[0], lit(C_A2B2), x0)
+    e('v_fmac_f32 v%d, %s, v%d', out[5], lit(C_A2B2), x1)
+    e('v_fmamk_f32 v%d, v%d, %s, v%d', out[1], t[1], lit(A_PT), t[0])
+    e('v_fmamk_f32 v%d, v%d, %s, v%d', out[2], t[1], lit(-A_PT), t[0])
+    e('v_fmamk_f32 v%d, v%d, %s, v%d', out[3], t[3], lit(B_PT), t[2])
+    e('v_fmamk_f32 v%d, v%d, %s, v%d', out[4], t[3], lit(-B_PT), t[2])
 
 
 def emit_transform(e, half):
@@ -493,16 +511,20 @@ def generate_inverse(r):
     T = lambda i, j: 26 + 6 * i + j    # v[26:49]  t[i][j], i = 0..3, j = 0..5
 
     def at(x, out, with_tail):
-        """x: six registers; out: four registers"""
+        """x: six registers (points 0, +a, -a, +b, -b, inf); out: four registers.  A^T[i][j] = point_j ^ i:
+        y0 = m0 + (m1 + m2) + (m3 + m4); y1 = a (m1 - m2) + b (m3 - m4); y2 = a^2 (m1 + m2) + b^2 (m3 + m4); y3 = a^3 (m1 - m2) + b^3 (m3 - m4) + m5"""
         e('v_add_f32 v%d, v%d, v%d', S12, x[1], x[2])
         e('v_sub_f32 v%d, v%d, v%d', D12, x[1], x[2])
         e('v_add_f32 v%d, v%d, v%d', S34, x[3], x[4])
         e('v_sub_f32 v%d, v%d, v%d', D34, x[3], x[4])
         e('v_add_f32 v%d, v%d, v%d', out[0], x[0], S12)
         e('v_add_f32 v%d, v%d, v%d', out[0], out[0], S34)                # (m0 + s12) + s34
-        e('v_fma_f32 v%d, 2.0, v%d, v%d', out[1], D34, D12)
-        e('v_fma_f32 v%d, 4.0, v%d, v%d', out[2], S34, S12)
-        e('v_fmamk_f32 v%d, v%d, 0x41000000, v%d', out[3], D34, D12)             # 8 d34 + d12 (8.0 is no inline constant)
+        e('v_mul_f32 v%d, %s, v%d', out[1], lit(A_PT), D12)
+        e('v_mul_f32 v%d, %s, v%d', out[2], lit(A_PT ** 2), S12)
+        e('v_mul_f32 v%d, %s, v%d', out[3], lit(A_PT ** 3), D12)
+        e('v_fmac_f32 v%d, %s, v%d', out[1], lit(B_PT), D34)
+        e('v_fmac_f32 v%d, %s, v%d', out[2], lit(B_PT ** 2), S34)
+        e('v_fmac_f32 v%d, %s, v%d', out[3], lit(B_PT ** 3), D34)
         e('v_add_f32 v%d, v%d, v%d', out[3], out[3], x[5])
 
     for j in range(6):

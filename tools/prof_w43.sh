@@ -3,7 +3,7 @@
 # directly after `--`.  Usage on the GPU box, from the repo root: tools/prof_w43.sh <tag> <forms> [N,C,K,H,W ...]
 set -e
 tag=${1:-r05}
-forms=${2:-0,8}
+forms=${2:-0}
 shift || true
 shift || true
 out=gpurun_out/prof_w43_$tag

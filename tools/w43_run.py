@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launches the F(4x4, 3x3) kernel a few times per shape and form, for rocprofv3 (tools/prof_w43.sh).
-Usage: python3 tools/w43_run.py forms shapes   e.g.  0,8 64,256,256,32,32 64,512,1024,16,16"""
+Usage: python3 tools/w43_run.py forms shapes   e.g.  0 64,256,256,32,32   (forms: 0, or 101-112 in the tools build) 64,512,1024,16,16"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

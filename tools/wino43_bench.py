@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Winograd F(4x4, 3x3) prototype (csrc/wino43_conv.hip.inc) against the F(2x2, 3x3) kernel on the bi-TAI layers with C >= 128 and
-K >= 128: error against an fp64 convolution and time per call, same process, alternating.  Usage: python tools/wino43_bench.py [--quick] [--waves4]"""
+K >= 128: error against an fp64 convolution and time per call, same process, alternating.  Usage: python tools/wino43_bench.py [--quick]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -40,8 +40,6 @@ def timed(fn, n=20):
 
 
 quick = '--quick' in sys.argv
-if '--waves4' in sys.argv:          # the one-wave-per-SIMD form of the F(4x4, 3x3) kernel (default: 8 waves, two per SIMD)
-    assert L.tai_conv3x3_wino43_set_waves(4) == 8
 shapes = [(1, 4, 64, 4, 4), (2, 8, 70, 12, 12), (3, 128, 128, 8, 20), (2, 12, 64, 16, 16)]
 if not quick:
     shapes += [(64, 128, 128, 64, 64), (64, 256, 256, 32, 32), (64, 128, 256, 32, 32), (64, 512, 256, 32, 32), (64, 256, 128, 64, 64),

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The forms of the F(4x4, 3x3) kernel against each other and against F(2x2, 3x3), same process, alternating rounds:
-0 = generated chunk loop (tools/gen_wino43_asm.py), 8 / 4 = round 4's compiler-scheduled forms.
+"""The F(4x4, 3x3) kernel (generated chunk loop, tools/gen_wino43_asm.py) against F(2x2, 3x3), same process, alternating rounds, with the
+error of each against a float64 convolution where that is cheap.  (Until the middle of round 5 this also timed round 4's compiler-scheduled
+forms; they are no longer in the library -- profiles/r05_wino43_generated_ablation.txt holds that comparison.)
 Usage: python tools/wino43_forms_bench.py [rounds]"""
 import os
 import sys
@@ -49,21 +50,14 @@ for (N, C, K, H, W) in shapes:
     w = (torch.randn(K, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** .5).cuda()
     b = torch.randn(K, generator=g).cuda()
     r43, r23 = make(43, x, w, b), make(23, x, w, b)
-    outs = {}
-    for form in (0, 8):
-        L.tai_conv3x3_wino43_set_waves(form)
-        outs[form] = r43().clone()
-    y23 = r23().clone()
-    scale = float(y23.abs().max())
-    err = {f: float((outs[f] - y23).abs().max()) / scale for f in outs}
+    y43, y23 = r43().clone(), r23().clone()
+    n = min(N, 4)
+    ref = torch.relu(F.conv2d(x[:n].double(), w.double(), b.double(), padding=1))
+    mag = float(ref.abs().max())
+    e43, e23 = float((y43[:n].double() - ref).abs().max()) / mag, float((y23[:n].double() - ref).abs().max()) / mag
     fl = 2.0 * N * K * C * 9 * H * W
     for rnd in range(rounds):
-        t = {}
-        for form in (0, 8):
-            L.tai_conv3x3_wino43_set_waves(form)
-            t[form] = timed(r43)
-        t23 = timed(r23)
-        print('x(%d,%d,%d,%d)->%d round %d  generated %.1f us (%.0f TF direct, %.3f of the fp32 MFMA peak)  r04 eight-wave %.1f us  F(2x2) %.1f us   '
-              'generated / r04 %.3f   | vs F(2x2): generated %.2e  r04 %.2e' %
-              (N, C, H, W, K, rnd, t[0], fl / t[0] / 1e6, fl / 4 / t[0] / 1e6 / 157.3, t[8], t23, t[8] / t[0], err[0], err[8]), flush=True)
-L.tai_conv3x3_wino43_set_waves(0)
+        t43, t23 = timed(r43), timed(r23)
+        print('x(%d,%d,%d,%d)->%d round %d  F(4x4) %.1f us (%.0f TF direct, %.3f of the fp32 MFMA peak)  F(2x2) %.1f us   F(2x2) / F(4x4) %.3f   '
+              '| max error / max |y| against float64: F(4x4) %.2e  F(2x2) %.2e' %
+              (N, C, H, W, K, rnd, t43, fl / t43 / 1e6, fl / 4 / t43 / 1e6 / 157.3, t23, t23 / t43, e43, e23), flush=True)

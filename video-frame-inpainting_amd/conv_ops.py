@@ -68,18 +68,21 @@ def get_winograd_arithmetic():
 
 
 _WINO_TILE = [4]
-WINO43_MIN_CHANNELS = 128        # F(4x4, 3x3) only where both C and K are at least this (profiles/r04_wino_f43_study.txt: parity-neutral there)
+WINO43_MIN_CHANNELS = 64         # F(4x4, 3x3) where both C and K are at least this: every 3x3 layer of MC-Net but the first and the last.  (128 until
+                                 # the kernel moved from Lavin's interpolation points to (0, +-3/4, +-3/2, inf), whose per-layer rounding is ~4x lower:
+                                 # with it the end-to-end error against the CPU oracle is the F(2x2) one on every config at 64 as well --
+                                 # profiles/r05_wino_f43_points_study.txt, r05_wino43_min_channels.txt; 49.7 -> 46.75 ms on the configs[1] forward)
 WINO43_MIN_WORKGROUPS = 150      # ... and where its 64-channel x 32-tile workgroups occupy most of the chip (round 5's kernel, same box, the
                                  # replayed configs[1] forward: 400: 51.11 ms, 256: 50.78, 150: 50.57, 100: 51.32, 64: 51.75 -- tools/w43_threshold_ab.py)
 
 
 def set_winograd_tile(m):
-    """Output tile of the Winograd 3x3 convolutions of the inference path: 4 (default since the end of round 4): F(4x4, 3x3),
-    csrc/wino43_conv.hip.inc, on the layers with C >= 128 and K >= 128 and enough workgroups -- 1.78x fewer MFMAs, fp32 operands on the
-    fp32 MFMA as everywhere else; its rounding error is ~7x F(2x2, 3x3)'s per layer, and restricted to those layers the forward's
-    end-to-end error against the CPU oracle is unchanged on every config (profiles/r04_wino_f43_study.txt, r04_wino43_default_parity.txt)
-    -- and F(2x2, 3x3), csrc/wino_conv.hip.inc, on every other layer; or 2: F(2x2, 3x3) on every layer (the arithmetic of rounds 1-3).
-    The displaced-read 5x5 / 7x7 layers and everything under autograd are F(2x2, 3x3) either way.  A hipGraph captured before a switch
+    """Output tile of the Winograd 3x3 convolutions: 4 (default since the end of round 4): F(4x4, 3x3), csrc/wino43_conv.hip.inc, on the
+    layers with C >= 64 and K >= 64 (WINO43_MIN_CHANNELS; the layers marked by mark_outside_recurrence at any width) and enough workgroups
+    -- 1.78x fewer MFMAs, fp32 operands on the fp32 MFMA as everywhere else; on its interpolation points (0, +-3/4, +-3/2, inf) the
+    rounding error is ~3-4x F(2x2, 3x3)'s per layer and the forward's end-to-end error against the CPU oracle is that of F(2x2, 3x3) on
+    every config (profiles/r05_wino_f43_points_study.txt, r05_wino43_min_channels.txt) -- and F(2x2, 3x3), csrc/wino_conv.hip.inc, on
+    every other layer; or 2: F(2x2, 3x3) on every layer (the arithmetic of rounds 1-3).  A hipGraph captured before a switch
     keeps replaying what it captured.  Returns the previous value."""
     if m not in (2, 4):
         raise ValueError(m)
@@ -92,11 +95,10 @@ def get_winograd_tile():
 
 
 def mark_outside_recurrence(module):
-    """Tell the dispatch that ``module``'s 3x3 layers may take F(4x4, 3x3) whatever their width.  F(4x4, 3x3)'s rounding is ~7x
-    F(2x2, 3x3)'s per layer; inside MC-Net's recurrence (every prediction is the next step's input) that only stays invisible on the
-    layers with C, K >= 128, but the kernel network and the merge residuals feed the separable convolution once per output frame:
-    with all of them on the 4 x 4 tile the forward's end-to-end error against float64 is that of the round-4 default (pred 2.4e-6 against
-    2.4e-6 at T = 5, 8.2e-6 against 6.6e-6 at T = 10, pred_forward / pred_backward untouched: profiles/r05_wino_f43_policy_study.txt).
+    """Tell the dispatch that ``module``'s 3x3 layers may take F(4x4, 3x3) below WINO43_MIN_CHANNELS too (from 16 input channels).  The
+    kernel network and the merge residuals feed the separable convolution once per output frame, outside MC-Net's recurrence (where
+    every prediction is the next step's input): with all of them on the 4 x 4 tile the forward's end-to-end error against float64 is
+    unchanged (profiles/r05_wino_f43_policy_study.txt, measured with Lavin's points, whose rounding was ~4x the present ones').
     TAIFillInModel marks kernelnet and merge_residual{1,2,3} (tai.py)."""
     for p in module.parameters():
         p._tai_f43_any_width = True

@@ -685,14 +685,14 @@ int tai_conv3x3_wino43_transform_weights(const float* weight, float* U, int K, i
     return check_launch("wino43_transform_weights");
 }
 
-// form of the F(4x4, 3x3) kernel: 0 (default) the generated chunk loop (eight waves, csrc/wino43_chunkloop.inc); 8 / 4: round 4's
-// compiler-scheduled forms with eight / four waves per workgroup (A/B)
+// 0: the kernel (generated chunk loop); 101..112 (tools build only): timing ablations / schedule variants of it.  Round 4's compiler-
+// scheduled forms (waves 8 / 4) are gone with their transform constants (profiles/r04_wino43_prototype.txt, r05_wino43_forms.txt keep the A/B).
 static std::atomic<int> g_wino43_waves{0};
 int tai_conv3x3_wino43_set_waves(int waves) {
-#ifdef TAI_TIMING_VARIANTS   // 101..109: ablations of the generated loop (timing only, wrong results; tools/gen_wino43_asm.py ABLATIONS)
+#ifdef TAI_TIMING_VARIANTS   // (timing only, wrong results; tools/gen_wino43_asm.py ABLATIONS)
     if (waves >= 101 && waves <= 112) return g_wino43_waves.exchange(waves, std::memory_order_relaxed);
 #endif
-    if (waves != 0 && waves != 4 && waves != 8) return -1;
+    if (waves != 0) return -1;
     return g_wino43_waves.exchange(waves, std::memory_order_relaxed);
 }
 
@@ -700,12 +700,10 @@ static int wino43_forward_impl(const float* const* xs, int nparts, const float* 
                                int W, int act, void* hip_stream, float* ypool = nullptr, const float* addx = nullptr, float* y2 = nullptr) {
     if (!xs || !xs[0] || !U || !bias || !y || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || nparts < 1 || nparts > 4)
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: bad argument (1 to 4 input parts)");
-    const int form = g_wino43_waves.load(std::memory_order_relaxed);
     // one tensor: any C (the transformed weights of the channels past C are zero and the loads of those channels past the tensor's end
-    // return 0; inside it they read the next image's first channels, finite values times zero) -- the generated form only
+    // return 0; inside it they read the next image's first channels, finite values times zero)
     const bool ragged = nparts == 1 && C % wino43::KC != 0;
-    if (H % 4 != 0 || W % 4 != 0 || C % nparts != 0 || (!ragged && (C / nparts) % wino43::KC != 0) || (ragged && (form == 4 || form == 8)) ||
-        act < 0 || act > 2)
+    if (H % 4 != 0 || W % 4 != 0 || C % nparts != 0 || (!ragged && (C / nparts) % wino43::KC != 0) || act < 0 || act > 2)
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: needs H and W multiples of 4, the channels of a part a multiple of 4 (any C for one part), act in {0, 1, 2}");
     if ((long long)N * C * H * W >= (1LL << 29) || (long long)N * K * H * W >= (1LL << 29))
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino43: tensor too large (2^29 elements or more)");
@@ -721,13 +719,6 @@ static int wino43_forward_impl(const float* const* xs, int nparts, const float* 
     const long long tiles = (long long)N * (H / 4) * (W / 4);
     const long long tblocks = (tiles + wino43::TN - 1) / wino43::TN;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-#define TAI_W43_LAUNCH(A, W8, E)                                                                                                \
-    {                                                                                                                           \
-        auto kern = wino43::conv3x3<A, W8, E>;                                                                                  \
-        if (int rc = allow_lds(kern, wino43::LDS_BYTES)) return rc;                                                             \
-        hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(W8 ? 512 : 256), wino43::LDS_BYTES, s, p[0], p[1], p[2], p[3], \
-                           cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, ypool, addx, y2);                          \
-    }
 #define TAI_W43_LAUNCH_GEN(A, E)                                                                                                \
     {                                                                                                                           \
         auto kern = wino43::conv3x3_gen<A, E>;                                                                                  \
@@ -752,24 +743,13 @@ static int wino43_forward_impl(const float* const* xs, int nparts, const float* 
     }
 #undef TAI_W43_LAUNCH_VAR
 #endif
-    if (g_wino43_waves.load(std::memory_order_relaxed) == 0) {      // the generated chunk loop (default)
-        if (ypool) {
-            if (act == 0) TAI_W43_LAUNCH_GEN(0, 1) else TAI_W43_LAUNCH_GEN(1, 1)
-        } else if (addx) {
-            if (y2) TAI_W43_LAUNCH_GEN(0, 2) else TAI_W43_LAUNCH_GEN(0, 3)
-        } else {
-            if (act == 0) TAI_W43_LAUNCH_GEN(0, 0) else if (act == 1) TAI_W43_LAUNCH_GEN(1, 0) else TAI_W43_LAUNCH_GEN(2, 0)
-        }
-    } else if (ypool) {                            // second outputs: the eight-wave form only
-        if (act == 0) TAI_W43_LAUNCH(0, true, 1) else TAI_W43_LAUNCH(1, true, 1)
+    if (ypool) {
+        if (act == 0) TAI_W43_LAUNCH_GEN(0, 1) else TAI_W43_LAUNCH_GEN(1, 1)
     } else if (addx) {
-        if (y2) TAI_W43_LAUNCH(0, true, 2) else TAI_W43_LAUNCH(0, true, 3)
-    } else if (g_wino43_waves.load(std::memory_order_relaxed) == 8) {
-        if (act == 0) TAI_W43_LAUNCH(0, true, 0) else if (act == 1) TAI_W43_LAUNCH(1, true, 0) else TAI_W43_LAUNCH(2, true, 0)
+        if (y2) TAI_W43_LAUNCH_GEN(0, 2) else TAI_W43_LAUNCH_GEN(0, 3)
     } else {
-        if (act == 0) TAI_W43_LAUNCH(0, false, 0) else if (act == 1) TAI_W43_LAUNCH(1, false, 0) else TAI_W43_LAUNCH(2, false, 0)
+        if (act == 0) TAI_W43_LAUNCH_GEN(0, 0) else if (act == 1) TAI_W43_LAUNCH_GEN(1, 0) else TAI_W43_LAUNCH_GEN(2, 0)
     }
-#undef TAI_W43_LAUNCH
 #undef TAI_W43_LAUNCH_GEN
     return check_launch("conv3x3_wino43");
 }
