@@ -176,20 +176,14 @@ def test_training_step_full_width_at_the_32_clip_dispatch(tmp_path, monkeypatch,
     """The same full-width B = 2 step with every convolution routed as at configs[2]'s 32 clips per GPU (tests/conftest.py:
     DispatchAt): the ConvLSTM's 512 -> 1024 at 16 x 16, CombLayers, ContentEnc / DecCnn's 256-channel layers at 32 x 32, Residual 3 and
     the kernel network's 8 x 8 / 4 x 4 layers run _WinoConv3x3 / _WinoConv3x3Parts / tai_conv3x3_wino_wrw where the default thresholds
-    send a 2-clip batch to MIOpen (conv_ops.WINO_MIN_WORKGROUPS).  Same oracle, same bounds; and no ATen convolution ran outside the
-    discriminator's four 4 x 4 stride-2 layers (environments.py:348-379, mcnet.py:259-294)."""
+    send a 2-clip batch to MIOpen (conv_ops.WINO_MIN_WORKGROUPS).  Same oracle, same bounds; and no ATen convolution ran at all
+    (environments.py:348-379, mcnet.py:259-294, SNDiscriminator.py:113-133)."""
     from conftest import miopen_convolutions
     _, prof = _step_and_compare(tmp_path, monkeypatch, gf_dim=64, kf_dim=32, df_dim=64, B=2, profile=True, tag='32-clip dispatch')
+    # since round 5 that includes the discriminator (its 4 x 4 stride-2 layers as 3 x 3 layers on space-to-depth planes) and the weight
+    # gradients of the 8 x 8 / 4 x 4 layers (rows widened to the weight-gradient kernel's 16 pixels): no ATen convolution in the update
     convs = miopen_convolutions(prof)
-    weight_of = lambda c: tuple(c[1][2 if 'backward' in c[0] else 1])
-    outside = [c for c in convs if weight_of(c)[-2:] != (4, 4)]
-    # what is left outside the discriminator: the WEIGHT gradients of the kernel network's 8 x 8 and 4 x 4 layers -- tai_conv3x3_wino_wrw
-    # takes rows of 16 pixels (conv_ops.wino_weight_grad: W % 16 == 0), so these go to aten.convolution_backward at every batch size,
-    # 32 clips included: the route configs[2] takes, compared with the oracle here as everything else
-    small = [c for c in outside if c[0] == 'aten::convolution_backward' and c[1][0][-1] < 16 and weight_of(c)[-2:] == (3, 3)]
-    shapes = sorted(set((c[0], tuple(c[1][0]), weight_of(c)) for c in outside))
-    print('ATen convolutions: %d in the discriminator (4 x 4 stride 2), %d outside it: %s' % (len(convs) - len(outside), len(outside), shapes))
-    assert convs and len(small) == len(outside), [c for c in outside if c not in small][:8]
+    assert not convs, sorted(set((c[0], tuple(c[1][0])) for c in convs))
     r = dispatch_at_32_clips.routes
     print('routes taken: %s' % r)
     assert r['wino'] > 100
@@ -442,14 +436,26 @@ def test_sn_power_iteration_kernel_matches_reference_run(golden_dir, Ip):
     np.testing.assert_allclose(layer.weight.detach().cpu().numpy(), (W / float(sigma)).numpy(), rtol=5e-6, atol=1e-9)
 
 
+def _force_in_tree_routes(monkeypatch):
+    """Small reference-run shapes through the routes of the training batch: every 3x3 form the in-tree Winograd kernels can take, they take
+    (the discriminator's 4x4 stride-2 layers as 3x3 layers on space-to-depth planes: sn_discriminator._s2d_applies)."""
+    from video_frame_inpainting_amd import conv_ops
+    monkeypatch.setattr(conv_ops, 'WINO_MIN_WORKGROUPS', 1)
+    monkeypatch.setattr(conv_ops, 'WINO43_MIN_WORKGROUPS', 1)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize('in_tree', [False, True])
 @pytest.mark.parametrize('tag, c_dim', [('disc_gray', 1), ('disc_color', 3)])
-def test_gpu_discriminator_matches_reference_run_over_two_calls(golden_dir, tag, c_dim):
+def test_gpu_discriminator_matches_reference_run_over_two_calls(golden_dir, tag, c_dim, in_tree, monkeypatch):
     """The product's all-windows-in-one-pass discriminator (renormalisations up front, one factor per window) against
     the reference's window-by-window SNDiscriminator.forward (:140-159) over two consecutive calls: logits, the
-    in-place renormalised weights and the persistent u vectors."""
+    in-place renormalised weights and the persistent u vectors.  ``in_tree``: the convolutions on the Winograd kernels (space-to-depth
+    form) as at the training batch, instead of MIOpen's, which these 32 x 32 shapes take by default."""
     import os
     from video_frame_inpainting_amd.sn_discriminator import SNDiscriminator
+    if in_tree:
+        _force_in_tree_routes(monkeypatch)
     z = np.load(os.path.join(golden_dir, 'sn_disc.npz'))
     w0, u0 = _sn_group(z, tag + '/w0/'), _sn_group(z, tag + '/u0/')
     disc = SNDiscriminator((32, 32), c_dim, 3, 4, 3)
@@ -471,10 +477,13 @@ def test_gpu_discriminator_matches_reference_run_over_two_calls(golden_dir, tag,
 
 
 @pytest.mark.gpu
-def test_gpu_discriminator_gradients_match_reference_run_single_window(golden_dir):
+@pytest.mark.parametrize('in_tree', [False, True])
+def test_gpu_discriminator_gradients_match_reference_run_single_window(golden_dir, in_tree, monkeypatch):
     import os
     import torch.nn.functional as Fn
     from video_frame_inpainting_amd.sn_discriminator import SNDiscriminator
+    if in_tree:
+        _force_in_tree_routes(monkeypatch)
     z = np.load(os.path.join(golden_dir, 'sn_disc.npz'))
     w0, u0 = _sn_group(z, 'disc_grad/w0/'), _sn_group(z, 'disc_grad/u0/')
     want = _sn_group(z, 'disc_grad/grad/')
@@ -496,3 +505,59 @@ def test_gpu_discriminator_gradients_match_reference_run_single_window(golden_di
         assert float((p.grad.cpu() - want[k]).abs().max()) <= 1e-3 * scale, (k, float((p.grad.cpu() - want[k]).abs().max()), scale)
     gf = z['disc_grad/grad_frames']
     assert float(np.abs(frames.grad.cpu().numpy() - gf).max()) <= 1e-3 * float(np.abs(gf).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(13, 2, 64, 128, 64), (13, 2, 3, 64, 128), (13, 32, 128, 256, 32), (13, 32, 256, 512, 16)])
+def test_discriminator_layer_on_space_to_depth_planes_matches_the_direct_form(shape, monkeypatch):
+    """One 4x4 stride-2 layer + LeakyReLU of the sliding-window discriminator (SNDiscriminator.py:113-133) as the 3x3 layer over
+    space-to-depth planes on the in-tree Winograd kernels (forward, input gradient, weight and bias gradient) against float64 direct
+    convolutions of the same operands, next to the MIOpen route the layer took until round 5; the in-tree gradients are bit-reproducible."""
+    import torch.nn.functional as Fn
+    from conftest import miopen_convolutions
+    from video_frame_inpainting_amd import conv_ops, sn_discriminator as snd
+    nw, B, C, K, H = shape
+    g = torch.Generator().manual_seed(C + K + H)
+    x = torch.randn(nw * B, C, H, H, generator=g).to(DEV)
+    w = (torch.randn(K, C, 4, 4, generator=g) * (2.0 / (16 * C)) ** 0.5).to(DEV)
+    b = (0.1 * torch.randn(K, generator=g)).to(DEV)
+    inv = (0.5 + torch.rand(nw, generator=g)).to(DEV)
+    gy = torch.randn(nw * B, K, H // 2, H // 2, generator=g).to(DEV)
+    if B == 2:
+        monkeypatch.setattr(conv_ops, 'WINO_MIN_WORKGROUPS', 1)
+        monkeypatch.setattr(conv_ops, 'WINO43_MIN_WORKGROUPS', 1)
+
+    def run(route):
+        with monkeypatch.context() as mp:
+            if route == 'direct':
+                mp.setattr(snd, '_s2d_applies', lambda *a: False)
+            xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU], record_shapes=True) as prof:
+                y = snd._WindowScaledConvLReLU.apply(xr, wr, wr.detach(), br, inv, nw, (2, 2), (1, 1), 0.2)
+                y.backward(gy)
+            return (y.detach(), xr.grad, wr.grad, br.grad), miopen_convolutions(prof)
+
+    got, convs = run('s2d')
+    assert not convs, convs                          # every convolution of the layer ran in-tree (the 8 x 8 layer's weight gradient on widened rows)
+    again, _ = run('s2d')
+    assert all(torch.equal(a, c) for a, c in zip(got, again))
+    old, convs_old = run('direct')
+    assert convs_old
+    xd, wd, bd = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    z = Fn.conv2d(xd, wd, None, 2, 1)
+    z = (z.view(nw, B, -1) * inv.double().view(nw, 1, 1)).view_as(z) + bd.view(1, -1, 1, 1)
+    yd = Fn.leaky_relu(z, 0.2)
+    # the fp32 routes may put a pre-activation within rounding of 0 on the other side of the kink: differentiate the float64 form with
+    # the product's sides (its gradient mask) so that the comparison is about the convolutions
+    side = (got[0] > 0).double()
+    slope = side + 0.2 * (1 - side)
+    (z * slope).backward(gy.double())
+    # the weight gradient takes the pre-activation gradient WITHOUT the window's factor: every window differentiates with respect to its own
+    # weight tensor w0 * inv_scale[t] and the results accumulate in the parameter (_WindowScaledConv's docstring; SNDiscriminator.py:60-68)
+    wu = w.double().requires_grad_()
+    Fn.conv2d(x.double(), wu, None, 2, 1).backward(gy.double() * slope)
+    for name, a, o, r in zip(('y', 'gx', 'gw', 'gb'), got, old, (yd.detach(), xd.grad, wu.grad, bd.grad)):
+        scale = float(r.abs().max())
+        e_new, e_old = float((a.double() - r).abs().max()) / scale, float((o.double() - r).abs().max()) / scale
+        print('%s %s: in-tree %.2e  MIOpen %.2e of the maximum' % (shape, name, e_new, e_old))
+        assert e_new <= 2e-5, (name, e_new, e_old)

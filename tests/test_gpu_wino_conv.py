@@ -353,7 +353,8 @@ def test_general_entry_point_rejects_bad_arguments():
 # (N, C, K, H, W): channel counts that are not multiples of 8 / 16 / 64, several 64-blocks, one chunk per split, many
 # chunks per split, tile rows of exactly one chunk (W = 16), the bi-TAI shapes
 WRW_SHAPES = [(1, 8, 8, 2, 16), (2, 16, 16, 8, 16), (3, 20, 51, 12, 32), (1, 65, 64, 16, 16), (5, 13, 70, 6, 48), (7, 9, 3, 4, 16),
-              (2, 64, 64, 128, 128), (4, 512, 128, 16, 16), (3, 128, 130, 32, 32), (32, 64, 64, 64, 64)]
+              (2, 64, 64, 128, 128), (4, 512, 128, 16, 16), (3, 128, 130, 32, 32), (32, 64, 64, 64, 64),
+              (6, 24, 40, 8, 8), (5, 16, 9, 4, 4), (3, 8, 8, 2, 2), (2, 40, 24, 6, 12)]      # rows of fewer than 16 pixels: widened with zeros
 
 
 def _weight_grad_fp64(x, go):
@@ -435,7 +436,7 @@ def test_wino_weight_gradient_sees_the_zero_padding_and_every_tap():
 
 def test_wino_weight_gradient_declines_unsupported_shapes():
     from video_frame_inpainting_amd import _native, conv_ops
-    x = torch.randn(1, 8, 6, 24, device='cuda')                   # W not a multiple of 16
+    x = torch.randn(1, 8, 6, 24, device='cuda')                   # W above 16 and not a multiple of 16
     assert conv_ops.wino_weight_grad(x, torch.randn(1, 8, 6, 24, device='cuda')) is None
     x = torch.randn(1, 8, 5, 16, device='cuda')                   # odd H
     assert conv_ops.wino_weight_grad(x, torch.randn(1, 8, 5, 16, device='cuda')) is None

@@ -448,6 +448,22 @@ def _conv3x3_autograd_launch(x, weight, eff_transposed, bias, N, Ci, Co, H, W, a
     return _wino_launch(x, _wino_weights(weight, eff_transposed), bias, N, Ci, Co, H, W, act)
 
 
+def wino_conv3x3_plain(x, weight, transposed=False):
+    """conv2d(x, w_eff, padding=1) without bias, activation or autograd on the in-tree Winograd kernels (F(4x4, 3x3) / F(2x2, 3x3) as
+    _conv3x3_autograd_launch chooses); ``transposed``: w_eff = the weight transposed and flipped (the input-gradient convolution of the
+    same weight).  None where neither kernel takes the shape -- the caller then keeps its own route.  (The discriminator's 4x4 stride-2
+    layers as 3x3 layers on space-to-depth planes: sn_discriminator.py.)"""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and weight.dtype == torch.float32 and x.dim() == 4):
+        return None
+    N, Ci, H, W = x.shape
+    Co = weight.shape[1] if transposed else weight.shape[0]
+    if (weight.shape[0] if transposed else weight.shape[1]) != Ci or tuple(weight.shape[2:]) != (3, 3):
+        raise ValueError('wino_conv3x3_plain: weight %s does not fit input %s' % (tuple(weight.shape), tuple(x.shape)))
+    if not ((WINO43_UNDER_AUTOGRAD and _wino43_ok(N, Ci, Co, H, W, 1, weight)) or _wino_ok(N, Ci, Co, H, W, 3, 3, 1)):
+        return None
+    return _conv3x3_autograd_launch(x, weight, transposed, _zero_bias(Co, x.device), N, Ci, Co, H, W, None)
+
+
 _ZERO_BIAS = {}
 
 
@@ -487,13 +503,18 @@ _WRW_WORKSPACE = _GrowingWorkspace()
 def wino_weight_grad(x, grad_out, with_bias=False, window=None):
     """dL/dw [Co, Ci, 3, 3] of y = conv2d(x, w, padding=1) from x [N, Ci, H, W] and dL/dy [N, Co, H, W], by
     ``tai_conv3x3_wino_wrw`` (Winograd-domain weight gradient on the fp32 MFMA pipe); None if the shape is not supported
-    (odd H, W not a multiple of 16, a tensor of 2 GiB or more).  ``with_bias``: returns (dw, dbias), the bias gradient
+    (odd H, W above 16 and not a multiple of 16, a tensor of 2 GiB or more; rows of fewer than 16 pixels are widened with zeros).  ``with_bias``: returns (dw, dbias), the bias gradient
     summed by the same kernel.  ``window`` = (in_oy, in_ox): x is a plane [N, Ci, in_h, in_w] that carries its own halo,
     with the pixel under output (0, 0) at (in_oy, in_ox) (the shifted-copy stack of the 5x5 / 7x7 layers).  The workspace
     (partial sums per workgroup) is kept per device and grows to the largest request."""
     N, Ci = x.shape[0], x.shape[1]
     Co, H, W = grad_out.shape[1], grad_out.shape[2], grad_out.shape[3]
     L = _native.lib()
+    if window is None and W % 16 and W < 16 and H % 2 == 0 and x.dtype == torch.float32 and grad_out.dtype == torch.float32:
+        # rows shorter than the kernel's 16 pixels (the 8 x 8 and 4 x 4 layers of the kernel network and of the discriminator): both planes
+        # widened to 16 columns with zeros -- the added output-gradient columns contribute nothing, the added input columns are the zero
+        # padding the last real column sees anyway -- instead of ATen's weight gradient, whose summation order changes from run to run
+        x, grad_out, W = F.pad(x, (0, 16 - W)), F.pad(grad_out, (0, 16 - W)), 16
     floats = L.tai_conv3x3_wino_wrw_workspace_floats(N, Ci, Co, H, W)
     if floats < 0 or N * Ci * x.shape[2] * x.shape[3] >= 2 ** 29:
         return None

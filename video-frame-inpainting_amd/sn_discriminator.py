@@ -100,6 +100,35 @@ class _SpectralNormalised(object):
         return w0, torch.cumprod(sigmas, 0).reciprocal_()
 
 
+def _conv_ops():
+    from . import conv_ops
+    return conv_ops
+
+
+# The discriminator's layers are 4x4, stride 2, padding 1 (SNDiscriminator.py:113-133).  On planes cut into 2 x 2 pixel blocks
+# (space-to-depth: channel (c, ry, rx) of block (qy, qx) = pixel (2 qy + ry, 2 qx + rx) of channel c) such a layer is a 3x3, stride-1,
+# padding-1 layer over 4 C channels: output o reads pixels 2 o - 1 ... 2 o + 2 = (block o - 1, r = 1), (o, 0), (o, 1), (o + 1, 0) per
+# dimension, so tap t of the 4-tap filter sits at (T, r) with 2 T + r = t + 1 and the two other (T, r) slots hold zeros.  That 3x3 layer
+# runs on the in-tree Winograd kernels -- F(4x4, 3x3) hands the fp32 MFMA 36 / 16 x 4 C = 9 C multiply-adds per output and filter
+# where the direct form has 16 C -- forward, input gradient (the same kernels with the weight transposed) and weight gradient
+# (tai_conv3x3_wino_wrw, then folded back to [K, C, 4, 4]); bit-reproducible, which MIOpen's backward kernels are not.
+def _s2d_applies(x, w, stride, padding):
+    return (x.is_cuda and x.dtype == torch.float32 and tuple(w.shape[2:]) == (4, 4) and tuple(stride) == (2, 2) and tuple(padding) == (1, 1)
+            and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0)
+
+
+def _s2d_weight(w):
+    """[K, C, 4, 4] -> the 3x3 weight [K, 4 C, 3, 3] over space-to-depth channels (c, ry, rx) (F.pixel_unshuffle's order)."""
+    K, C = w.shape[0], w.shape[1]
+    return F.pad(w, (1, 1, 1, 1)).view(K, C, 3, 2, 3, 2).permute(0, 1, 3, 5, 2, 4).reshape(K, 4 * C, 3, 3)
+
+
+def _s2d_weight_grad(g3, C):
+    """Gradient of the 3x3 form [K, 4 C, 3, 3] -> gradient of the 4x4 filter [K, C, 4, 4] (the structurally-zero slots dropped)."""
+    K = g3.shape[0]
+    return g3.view(K, C, 2, 2, 3, 3).permute(0, 1, 4, 2, 5, 3).reshape(K, C, 6, 6)[:, :, 1:5, 1:5].contiguous()
+
+
 class _WindowScaledConv(torch.autograd.Function):
     """y[t] = conv(x[t], w0) * inv_scale[t] + bias for the ``nw`` window groups stacked along the batch: the convolution
     of window t with the weight the reference holds at that moment, w0 * inv_scale[t] (SNDiscriminator.py:60-68), as ONE
@@ -143,20 +172,31 @@ class _WindowScaledConvLReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, w0, bias, inv_scale, nw, stride, padding, slope):
         from . import _native
-        y = F.conv2d(x, w0, None, stride, padding).contiguous()
+        xs = w3 = y = None
+        if _s2d_applies(x, w0, stride, padding):
+            xs, w3 = F.pixel_unshuffle(x, 2), _s2d_weight(w0)
+            y = _conv_ops().wino_conv3x3_plain(xs, w3)
+        if y is None:
+            xs = w3 = None
+            y = F.conv2d(x, w0, None, stride, padding).contiguous()
         N, Co, H, W = y.shape
         with torch.cuda.device(y.device):
             _native.check(_native.lib().tai_window_scale_bias_lrelu(
                 y.data_ptr(), bias.data_ptr(), inv_scale.data_ptr(), nw, N // nw, Co, H * W, float(slope),
                 torch.cuda.current_stream(y.device).cuda_stream), 'tai_window_scale_bias_lrelu')
-        ctx.save_for_backward(x, w0, inv_scale, y)
+        ctx.s2d = xs is not None
+        if ctx.s2d:
+            ctx.save_for_backward(x, w0, inv_scale, y, xs, w3)
+        else:
+            ctx.save_for_backward(x, w0, inv_scale, y)
         ctx.cfg = (nw, stride, padding, float(slope))
         return y
 
     @staticmethod
     def backward(ctx, g):
         from . import _native
-        x, w0, inv_scale, y = ctx.saved_tensors
+        x, w0, inv_scale, y = ctx.saved_tensors[:4]
+        xs, w3 = ctx.saved_tensors[4:] if ctx.s2d else (None, None)
         nw, stride, padding, slope = ctx.cfg
         g = g.contiguous()
         N, Co, H, W = g.shape
@@ -168,10 +208,20 @@ class _WindowScaledConvLReLU(torch.autograd.Function):
         gx = gw = gb = None
         conv_bwd = torch.ops.aten.convolution_backward
         if ctx.needs_input_grad[1]:
-            gw = conv_bwd(gz, x, w0, [Co], list(stride), list(padding), [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            if ctx.s2d:                 # the 3x3 layer's Winograd-domain weight gradient (and the bias gradient with it), folded back to 4x4
+                both = _conv_ops().wino_weight_grad(xs, gz, with_bias=bool(ctx.needs_input_grad[3]))
+                if both is not None:
+                    g3, gb = both if ctx.needs_input_grad[3] else (both, None)
+                    gw = _s2d_weight_grad(g3, x.shape[1])
+            if gw is None:
+                gw = conv_bwd(gz, x, w0, [Co], list(stride), list(padding), [1, 1], False, [0, 0], 1, [False, True, False])[1]
         if ctx.needs_input_grad[0]:
-            gx = conv_bwd(gs, x, w0, [Co], list(stride), list(padding), [1, 1], False, [0, 0], 1, [True, False, False])[0]
-        if ctx.needs_input_grad[3]:
+            gxs = _conv_ops().wino_conv3x3_plain(gs, w3, transposed=True) if ctx.s2d else None
+            if gxs is not None:
+                gx = F.pixel_shuffle(gxs, 2)
+            else:
+                gx = conv_bwd(gs, x, w0, [Co], list(stride), list(padding), [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[3] and gb is None:
             gb = gz.sum((0, 2, 3))
         return gx, gw, None, gb, None, None, None, None, None
 
