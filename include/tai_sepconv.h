@@ -163,6 +163,11 @@ int tai_conv3x3_wino_wrw_window(const float* x, const float* dy, float* dw, floa
 /* Load scheme of the weight-gradient kernel when W % 32 == 0: 1 (default) = chunk pairs over 16 consecutive tiles, whole
  * 128-byte lines per load; 0 = 8-tile chunks as for the other widths (same results, for A/B timing).  Returns the previous value. */
 int tai_conv3x3_wino_wrw_set_paired(int on);
+/* Transform domain of tai_conv3x3_wino_wrw, process-wide: 2 = F(2x2, 3x3) (csrc/wino_wrw.hip.inc), 4 (default) = F(4x4, 3x3) where H % 4 == 0 (and
+ * W % 16 == 0, no input window) -- 36 multiplies per 4 x 4 tile instead of 16 per 2 x 2 tile, the forward kernel's interpolation points
+ * (csrc/wino43_conv.hip.inc, conv3x3_wrw_gen); other shapes keep the F(2x2, 3x3) kernel.  Same interface, same workspace (the size query
+ * covers both), reproducible either way.  Returns the previous value, -1 for anything else. */
+int tai_conv3x3_wino_wrw_set_tile(int tile);
 
 /* Spectral normalisation of one discriminator layer, as the reference's SNConv2d / SNLinear do on every forward
  * (src/discriminators/SNDiscriminator.py:10-25 max_singular_value, :60-68 and :84-92 W.data <- W.data / sigma):

@@ -363,10 +363,31 @@ def _weight_grad_fp64(x, go):
     return torch.autograd.grad(F.conv2d(xd, wd, None, padding=1), wd, go.double())[0]
 
 
+@pytest.fixture
+def wrw_tile_2():
+    """the F(2x2, 3x3)-domain weight-gradient kernel for the tests of ITS properties (exact on integers, load schemes, input windows)"""
+    from video_frame_inpainting_amd import conv_ops
+    prev = conv_ops.set_weight_gradient_tile(2)
+    yield
+    conv_ops.set_weight_gradient_tile(prev)
+
+
+@pytest.mark.parametrize('tile', [4, 2])
 @pytest.mark.parametrize('shape', WRW_SHAPES)
-def test_wino_weight_gradient_matches_fp64(shape):
+def test_wino_weight_gradient_matches_fp64(shape, tile):
+    """tile 4 (default): the F(4x4, 3x3)-domain kernel where H % 4 == 0 (conv3x3_wrw_gen; other shapes fall to the F(2x2, 3x3) kernel, and
+    rows shorter than 16 pixels are widened first), tile 2: the F(2x2, 3x3) kernel everywhere."""
     from video_frame_inpainting_amd import conv_ops
     N, C, K, H, W = shape
+    prev = conv_ops.set_weight_gradient_tile(tile)
+    try:
+        _weight_gradient_matches_fp64(N, C, K, H, W)
+    finally:
+        assert conv_ops.set_weight_gradient_tile(prev) == tile
+
+
+def _weight_gradient_matches_fp64(N, C, K, H, W):
+    from video_frame_inpainting_amd import conv_ops
     g = torch.Generator().manual_seed(23)
     x = torch.randn(N, C, H, W, generator=g).cuda()
     go = torch.randn(N, K, H, W, generator=g).cuda()
@@ -385,7 +406,7 @@ def test_wino_weight_gradient_matches_fp64(shape):
     assert torch.equal(gb, conv_ops.wino_weight_grad(x, go, with_bias=True)[1])
 
 
-def test_wino_weight_gradient_paired_and_plain_chunks_agree():
+def test_wino_weight_gradient_paired_and_plain_chunks_agree(wrw_tile_2):
     """W % 32 == 0 takes the paired-chunk load scheme (whole 128-byte lines); the 8-tile scheme on the same operands sums the
     same products in another order."""
     from video_frame_inpainting_amd import _native, conv_ops
@@ -405,7 +426,7 @@ def test_wino_weight_gradient_paired_and_plain_chunks_agree():
         assert float((pb - qb).abs().max()) / scale <= 2e-5
 
 
-def test_wino_weight_gradient_exact_on_small_integers():
+def test_wino_weight_gradient_exact_on_small_integers(wrw_tile_2):
     """Integer-valued operands keep every Winograd intermediate exact in fp32 (the transforms only add, the 1/2 and 1/4
     factors of G^T . G are exact), so the result must equal the integer sums bit for bit."""
     from video_frame_inpainting_amd import conv_ops
@@ -418,20 +439,31 @@ def test_wino_weight_gradient_exact_on_small_integers():
     assert torch.equal(got.double(), ref)
 
 
-def test_wino_weight_gradient_sees_the_zero_padding_and_every_tap():
-    """One non-zero output-gradient pixel in a corner and one in the interior: dw[k, c, a, b] = x[c, y + a - 1, x + b - 1]
-    with zeros outside the image."""
+@pytest.mark.parametrize('tile', [4, 2])
+def test_wino_weight_gradient_sees_the_zero_padding_and_every_tap(tile):
+    """One non-zero output-gradient pixel in a corner, on an edge and in the interior: dw[k, c, a, b] = x[c, y + a - 1, x + b - 1]
+    with zeros outside the image -- the F(4x4, 3x3) kernel gets there without a halo (rows -1 / H through a zero-size buffer descriptor,
+    the columns left / right of a tile row through the coefficient of the edge value; two images and W = 32, so that chunks start, end
+    and lie inside tile rows) and is exact to rounding only (its constants are multiples of 1/64 and 1/81)."""
     from video_frame_inpainting_amd import conv_ops
-    N, C, K, H, W = 1, 8, 8, 8, 16
+    N, C, K, H, W = 2, 8, 8, 8, 32
     x = torch.arange(N * C * H * W, dtype=torch.float32).view(N, C, H, W).cuda() % 17 - 8
-    for (py, px) in ((0, 0), (H - 1, W - 1), (3, 7), (0, 9), (5, 0)):
-        go = torch.zeros(N, K, H, W, device='cuda')
-        go[0, 2, py, px] = 1.0
-        got = conv_ops.wino_weight_grad(x, go)
-        xp = F.pad(x, (1, 1, 1, 1))
-        want = torch.zeros(K, C, 3, 3, device='cuda')
-        want[2] = xp[0, :, py:py + 3, px:px + 3]
-        assert torch.equal(got, want), (py, px)
+    prev = conv_ops.set_weight_gradient_tile(tile)
+    try:
+        for n in (0, 1):
+            for (py, px) in ((0, 0), (H - 1, W - 1), (3, 7), (0, 9), (5, 0), (4, 15), (3, 16), (7, 31), (0, 31), (7, 0), (4, 4)):
+                go = torch.zeros(N, K, H, W, device='cuda')
+                go[n, 2, py, px] = 1.0
+                got = conv_ops.wino_weight_grad(x, go)
+                xp = F.pad(x, (1, 1, 1, 1))
+                want = torch.zeros(K, C, 3, 3, device='cuda')
+                want[2] = xp[n, :, py:py + 3, px:px + 3]
+                if tile == 2:
+                    assert torch.equal(got, want), (n, py, px)
+                else:
+                    assert float((got - want).abs().max()) <= 2e-5, (n, py, px, float((got - want).abs().max()))
+    finally:
+        conv_ops.set_weight_gradient_tile(prev)
 
 
 def test_wino_weight_gradient_declines_unsupported_shapes():
@@ -477,11 +509,21 @@ def test_5x5_and_7x7_training_form_gradients_match_autograd_of_conv2d(k, shape, 
         assert err <= tol, err
 
 
-def test_wino_weight_gradient_reads_a_haloed_plane_like_the_padded_tensor():
+@pytest.mark.parametrize('tile', [4, 2])
+def test_wino_weight_gradient_reads_a_haloed_plane_like_the_padded_tensor(tile):
     """tai_conv3x3_wino_wrw_window on a zero-framed copy of x (origin (1, 2) / (3, 4)) sums exactly the products of the
-    plain entry on x: the frame's zeros stand where the plain entry pads."""
+    plain entry on x: the frame's zeros stand where the plain entry pads.  (F(2x2, 3x3) kernel: the same bits; the F(4x4, 3x3) kernel
+    multiplies the halo's zeros where the plain entry skips the loads: equal to rounding.)"""
     from video_frame_inpainting_amd import conv_ops
     g = torch.Generator().manual_seed(41)
+    prev = conv_ops.set_weight_gradient_tile(tile)
+    try:
+        _haloed_plane_checks(conv_ops, g, tile)
+    finally:
+        conv_ops.set_weight_gradient_tile(prev)
+
+
+def _haloed_plane_checks(conv_ops, g, tile):
     for (N, C, K, H, W), (oy, ox) in (((3, 24, 40, 16, 32), (1, 2)), ((2, 16, 16, 8, 16), (3, 4)), ((2, 64, 72, 32, 64), (1, 2))):
         x = torch.randn(N, C, H, W, generator=g).cuda()
         go = torch.randn(N, K, H, W, generator=g).cuda()
@@ -489,7 +531,12 @@ def test_wino_weight_gradient_reads_a_haloed_plane_like_the_padded_tensor():
         plane[:, :, oy:oy + H, ox:ox + W] = x
         a, ab = conv_ops.wino_weight_grad(x, go, with_bias=True)
         b, bb = conv_ops.wino_weight_grad(plane, go, with_bias=True, window=(oy, ox))
-        assert torch.equal(a, b) and torch.equal(ab, bb)
+        if tile == 2:
+            assert torch.equal(a, b) and torch.equal(ab, bb)
+        else:
+            assert torch.equal(ab, bb) and float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+            ref = _weight_grad_fp64(x, go)
+            assert float((b.double() - ref).abs().max()) / (N * H * W) ** 0.5 <= 2e-5
     # a non-zero frame is read, not padded over
     plane = torch.randn(2, 16, 8 + 2, 16 + 4, generator=g).cuda()
     go = torch.randn(2, 16, 8, 16, generator=g).cuda()

@@ -86,6 +86,8 @@ def lit(x):
 
 
 C_A2B2, C_NSUM = A_PT ** 2 * B_PT ** 2, -(A_PT ** 2 + B_PT ** 2)       # rows 0 / inf: a^2 b^2 x0 - (a^2 + b^2) x2 + x4
+WRW = [False]          # generate the weight-gradient form (see the WRW section below): roles 0 / 1 transform input patches of 32 channels x 4 tiles,
+                       # role 2 transforms 64 x 4 output-gradient tiles (A dY A^T) instead of copying weights; the reduction runs over the tiles
 BLOCKS = [False]       # generate the displaced-read form (k x k filters as S x S blocks of 3 x 3 taps: see emit_patch_advance)
 SCHEDULE = {'xform_first', 'vmem_front'}   # the shipped schedule: the patch waves transform the next chunk FIRST (their SIMD partner has the
                        # matrix pipe to itself meanwhile; both then run MFMAs to the barrier together) and the next chunk's loads / DMA go out
@@ -213,14 +215,24 @@ def emit_block_flags(e):
     e('s_cselect_b32 s%d, s%d, 0', S_FLAGS, S_FLAGS)
 
 
-def emit_patch_row_load(e, r):
+def emit_patch_row_load(e, r, role=0):
     if 'noloads' in ABLATE:
+        return
+    if WRW[0]:
+        emit_wrw_row_load(e, r, role)
         return
     e('buffer_load_dwordx4 %s, v%d, s[%d:%d], s%d offen', quad(D_MID(r)), OFF_MID(r), S_DESC, S_DESC + 3, S_SOFF)
     e('buffer_load_dword v%d, v%d, s[%d:%d], s%d offen', D_EDGE(r), OFF_EDGE(r), S_DESC, S_DESC + 3, S_SOFF)
 
 
-def emit_patch_advance(e, tag):
+def emit_patch_advance(e, tag, role=0):
+    if WRW[0]:
+        emit_wrw_advance(e, tag, role)
+        return
+    emit_patch_advance_fwd(e, tag)
+
+
+def emit_patch_advance_fwd(e, tag):
     """the input state advances by one chunk: soffset += bytes per chunk.  At the end of a part (parts form): the next part's base,
     soffset 0.  Displaced-read form (BLOCKS: ONE tensor, a plane that carries its halo, read S x S times -- channel block (a, b)
     displaced by (3a, 3b) pixels, the k x k filters of MotionEnc cut into 3 x 3 blocks): at the end of a block the soffset restarts at
@@ -248,27 +260,40 @@ def emit_patch_advance(e, tag):
     e.label('SAMEPART_' + tag)
 
 
-def emit_patch_loads(e, tag):
+def load_rows(role):
+    return 4 if (WRW[0] and role == 2) else 6
+
+
+def emit_patch_loads(e, tag, role=0):
     """the 12 loads of the next patch rows (current part / soffset), then the state advances"""
-    for r in range(6):
-        emit_patch_row_load(e, r)
-    emit_patch_advance(e, tag)
+    for r in range(load_rows(role)):
+        emit_patch_row_load(e, r, role)
+    emit_patch_advance(e, tag, role)
 
 
-def bt_rows_half(e, half, x, out, t0, t1):
+def bt_rows_half(e, half, x, out, t0, t1, edge_coef=None):
     """the three B^T rows of a half applied to six values.  half 0: x = [x0, x1, x2, x3, x4] -> rows 0, +a, -a;
-    half 1: x = [x1, x2, x3, x4, x5] -> rows +b, -b, inf.  out: three destination registers.  6 instructions."""
+    half 1: x = [x1, x2, x3, x4, x5] -> rows +b, -b, inf.  out: three destination registers.  6 instructions.
+    ``edge_coef`` (weight-gradient form): a register with the coefficient of the edge value x0 (a^2 b^2, or 0 in the lanes whose left
+    neighbour column lies outside the image) / x5 (1, or 0): 6 / 7 instructions."""
     if half == 0:
         x0, x1, x2, x3, x4 = x
         e('v_fmamk_f32 v%d, v%d, %s, v%d', out[0], x2, lit(C_NSUM), x4)              # x4 - (a^2 + b^2) x2
         e('v_fmamk_f32 v%d, v%d, %s, v%d', t0, x2, lit(-B_PT ** 2), x4)              # p = x4 - b^2 x2
         e('v_fmamk_f32 v%d, v%d, %s, v%d', t1, x1, lit(-B_PT ** 2), x3)              # q = x3 - b^2 x1
-        e('v_fmac_f32 v%d, %s, v%d', out[0], lit(C_A2B2), x0)                        # row 0 = a^2 b^2 x0 - (a^2 + b^2) x2 + x4
+        if edge_coef is None:
+            e('v_fmac_f32 v%d, %s, v%d', out[0], lit(C_A2B2), x0)                    # row 0 = a^2 b^2 x0 - (a^2 + b^2) x2 + x4
+        else:
+            e('v_fmac_f32 v%d, v%d, v%d', out[0], edge_coef, x0)
         e('v_fmamk_f32 v%d, v%d, %s, v%d', out[1], t1, lit(A_PT), t0)                # row +a = p + a q
         e('v_fmamk_f32 v%d, v%d, %s, v%d', out[2], t1, lit(-A_PT), t0)               # row -a = p - a q
     else:
         x1, x2, x3, x4, x5 = x
-        e('v_fmamk_f32 v%d, v%d, %s, v%d', out[2], x3, lit(C_NSUM), x5)              # x5 - (a^2 + b^2) x3
+        if edge_coef is None:
+            e('v_fmamk_f32 v%d, v%d, %s, v%d', out[2], x3, lit(C_NSUM), x5)          # x5 - (a^2 + b^2) x3
+        else:
+            e('v_mul_f32 v%d, v%d, v%d', out[2], edge_coef, x5)
+            e('v_fmac_f32 v%d, %s, v%d', out[2], lit(C_NSUM), x3)
         e('v_fmamk_f32 v%d, v%d, %s, v%d', t0, x2, lit(-A_PT ** 2), x4)              # p = x4 - a^2 x2
         e('v_fmamk_f32 v%d, v%d, %s, v%d', t1, x1, lit(-A_PT ** 2), x3)              # q = x3 - a^2 x1
         e('v_fmac_f32 v%d, %s, v%d', out[2], lit(C_A2B2), x1)                        # row inf = a^2 b^2 x1 - (a^2 + b^2) x3 + x5
@@ -294,12 +319,19 @@ def bt_rows_all(e, x, out, t):
 
 
 def emit_transform(e, half):
+    if WRW[0]:
+        emit_wrw_transform(e, half)
+        return
+    emit_transform_fwd(e, half)
+
+
+def emit_transform_fwd(e, half, edge_coef=None):
     """B^T d B of this thread's three columns from the patch registers, written to the stage at v64 (V_W).
     R[r][c] = B^T row (3 half + c) applied to row r of d (row pass), V[i][c] = B^T row i applied to column c of R (column pass)."""
     for r in range(0 if 'noxform' in ABLATE else 6):
         m = D_MID(r)
         x = [D_EDGE(r), m, m + 1, m + 2, m + 3] if half == 0 else [m, m + 1, m + 2, m + 3, D_EDGE(r)]
-        bt_rows_half(e, half, x, [ROWP(r, 0), ROWP(r, 1), ROWP(r, 2)], TMP, TMP + 1)
+        bt_rows_half(e, half, x, [ROWP(r, 0), ROWP(r, 1), ROWP(r, 2)], TMP, TMP + 1, edge_coef)
     # column pass; results into v[16:33]: per row pair ip a quad (the half's two columns that share a position group) and a pair
     if half == 0:
         quad_cols, pair_col = (0, 1), 2
@@ -352,17 +384,20 @@ def emit_toggle(e, patch):
 def emit_role(e, role):
     """role 0 / 1: patch half A / B; role 2: weight copy"""
     tag = 'R%d' % role
-    patch = role < 2
+    patch = role < 2 or WRW[0]           # weight-gradient form: the former weight-copy waves load and transform output-gradient tiles
     e.label('ROLE_' + tag)
     if patch:
-        e('s_setprio 2')
+        if WRW[0]:
+            emit_wrw_role_start(e, role)
+        else:
+            e('s_setprio 2')
         # ---- prologue: patch rows of chunk 0, transformed into stage 0; the rows of chunk 1 requested
-        emit_patch_loads(e, tag + 'P0')
+        emit_patch_loads(e, tag + 'P0', role)
         e('s_waitcnt vmcnt(0)')
         emit_transform(e, role)                          # v64 = write base of stage 0
         e('s_cmp_lt_u32 s%d, 2', S_REM)
         e('s_cbranch_scc1 %s', e.ref('PRO_DONE_' + tag))
-        emit_patch_loads(e, tag + 'P1')
+        emit_patch_loads(e, tag + 'P1', role)
         e.label('PRO_DONE_' + tag)
         e('v_sub_u32 v%d, v%d, v%d', V_W, V_SW, V_W)   # the loop's transform writes the OTHER stage
         e('s_waitcnt lgkmcnt(0)')
@@ -390,8 +425,8 @@ def emit_role(e, role):
             emit_read(e, 1, 1)
             e('s_cmp_lt_u32 s%d, 3', S_REM)
             e('s_cbranch_scc1 %s', e.ref('PLAIN_NOREAD_' + tag))
-            emit_mfma_phase(e, lambda g: emit_patch_row_load(e, g) if g < 6 else None)
-            emit_patch_advance(e, tag + 'L')
+            emit_mfma_phase(e, lambda g: emit_patch_row_load(e, g, role) if g < load_rows(role) else None)
+            emit_patch_advance(e, tag + 'L', role)
             e('s_branch %s', e.ref('CHUNK_END_' + tag))
         else:
             e('s_cmp_lt_u32 s%d, 3', S_REM)                  # a chunk after that?
@@ -431,6 +466,10 @@ def emit_role(e, role):
     e('s_sub_u32 s%d, s%d, 1', S_REM, S_REM)
     e('s_cmp_lg_u32 s%d, 0', S_REM)
     e('s_cbranch_scc1 %s', e.ref('LOOP_' + tag))
+    if WRW[0] and role == 2:             # the four partial sums of the output-gradient values this lane has seen (bias gradient) -> v98
+        e('v_add_f32 v%d, v%d, v%d', W_BSUM, W_BSUM, W_BSUM + 1)
+        e('v_add_f32 v%d, v%d, v%d', W_BSUM + 2, W_BSUM + 2, W_BSUM + 3)
+        e('v_add_f32 v%d, v%d, v%d', W_BSUM_OUT, W_BSUM, W_BSUM + 2)
     e('s_branch %s', e.ref('END'))
 
 
@@ -444,6 +483,179 @@ def emit_dma_first(e):
         e('s_addc_u32 s%d, s%d, 0', S_WP + 1, S_WP + 1)
         if r < 8:
             e('s_add_u32 m0, m0, 0x1000')
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# WRW: the weight gradient of the same convolution in the same transform domain (csrc/wino43_conv.hip.inc, conv3x3_wrw_gen):
+#     dL/dU[pos][k][c] = sum over tiles of (A dY A^T)[pos][k][tile] * (B^T d B)[pos][c][tile],      dL/dg = G^T (dL/dU) G
+# -- the forward's GEMM with the roles renamed: M = 64 output channels, N = 32 INPUT CHANNELS, reduction = the tiles, 4 per chunk (four
+# consecutive tiles of a tile row: W % 16 == 0).  Roles 0 / 1 transform the input patches exactly as in the forward (thread = channel
+# tid % 32, tile (tid / 32) % 4, half tid / 128), role 2 (waves 4-7: tile wave % 4, lane = output channel) loads a 4 x 4 output-gradient
+# tile and writes its 36 transformed values as nine 16-byte A-operand quads.  A workgroup walks its run of chunks ("split") through the
+# images: per-lane offsets are fixed (channel plane, tile of the chunk, patch row), the scalar offset steps 64 bytes per chunk, 3 W rows at
+# the end of a tile row, the remaining planes at the end of an image.  The input planes carry no halo; instead
+#   * patch rows -1 / 4 of the first / last tile row: the buffer descriptor's size word is 0 for those two loads (uniform per chunk);
+#   * the column left of a tile row's first tile / right of its last: the coefficient of that value in B^T is a per-lane register (0 in
+#     the lanes of tile 0 / 3 of such a chunk, v_cndmask per chunk), and those lanes' edge loads are switched off by EXEC (image 0,
+#     channel 0, row 0 would read 4 bytes in front of the tensor, the last row of the last plane 4 bytes behind it).
+# Inputs (same registers as the forward): v[46:51] off_mid (role 2: v[46:49] the four rows of the tile), v[52:57] off_edge, v58 / v59
+# A / B read base, v60 LDS write base, v61 the masked lanes' edge coefficient (0, elsewhere a^2 b^2 / 1);  s[48:49] tensor base
+# (x - (W + 1) floats / dY), s50 tile rows per image, s51 tile rows left in the first image, s52 bytes from the end of an image's first plane
+# to the next image, s53 chunks left in the first tile row, s54 first scalar offset, s55 bit 0: sum the bias gradient, s56 bytes of the
+# tensor, s63 the size word of the loads of a row outside the image (0; s56 for an input plane that carries its own halo: all rows are read), s57 chunks per tile row, s58 chunks of this split, s59 3 W * 4, s[60:61] EXEC of the edge-column loads of a chunk that starts (half 0) / ends (half 1) a tile row, s62 role.
+W_IN_TH, W_IN_ROWS0, W_IN_IMGSKIP, W_IN_LEFT0, W_IN_SOFF0, W_IN_FLAGS, W_IN_EX0, W_IN_ROWOFF = S_IN + 2, S_IN + 3, S_IN + 4, S_IN + 5, S_IN + 6, S_IN + 7, S_IN + 12, S_IN + 15
+W_ROWS, W_TOPSZ, W_BOTSZ, W_EDGE_CUR, W_EDGE_PREV, W_EX = 72, 73, 74, 75, 77, 78
+W_COEF = TMP + 4            # v90
+W_FULL = TMP + 5            # v91: a^2 b^2 (half 0)
+W_BSUM = 88                 # role 2: v[88:91]
+W_BSUM_OUT = 98             # ... their sum, an output of the statement (the filter transform's temporaries end at v89)
+W_T = lambda p, j: 68 + 4 * (p - 1) + j          # role 2: first-pass results of points +-a, +-b (p = 1..4), column j
+W_E, W_O = 84, 85
+
+
+def litf(x):
+    """fp32 literal, rounded (the inverse-filter constants of G are not exactly representable)"""
+    return '0x%08x' % _struct.unpack('<I', _struct.pack('<f', float(x)))[0]
+
+
+def emit_wrw_edge_state(e, role):
+    """flags of the chunk the NEXT loads fetch: half 0: it starts a tile row (left neighbour column outside), half 1: it ends one"""
+    if role == 2:
+        return
+    if role == 0:
+        e('s_cmp_eq_u32 s%d, s%d', S_LEFT, S_CPP)
+    else:
+        e('s_cmp_eq_u32 s%d, 1', S_LEFT)
+    e('s_cselect_b64 s[%d:%d], s[%d:%d], -1', W_EX, W_EX + 1, W_IN_EX0, W_IN_EX0 + 1)
+    e('s_cselect_b32 s%d, 1, 0', W_EDGE_CUR)
+
+
+def emit_wrw_role_start(e, role):
+    if role == 2:
+        for i in range(4):
+            e('v_mov_b32 v%d, 0', W_BSUM + i)
+        return
+    for r in range(6):
+        e('v_mov_b32 v%d, 0', D_EDGE(r))          # lanes whose edge-column loads are switched off must never hold a stale NaN pattern
+    if role == 0:
+        e('v_mov_b32 v%d, %s', W_FULL, lit(C_A2B2))
+    emit_wrw_edge_state(e, role)
+
+
+def emit_wrw_row_load(e, r, role):
+    if role == 2:
+        e('buffer_load_dwordx4 %s, v%d, s[%d:%d], s%d offen', quad(16 + 4 * r), OFF_MID(r), S_DESC, S_DESC + 3, S_SOFF)
+        return
+    if r in (0, 5):
+        e('s_mov_b32 s%d, s%d', S_DESC + 2, W_TOPSZ if r == 0 else W_BOTSZ)
+    e('buffer_load_dwordx4 %s, v%d, s[%d:%d], s%d offen', quad(D_MID(r)), OFF_MID(r), S_DESC, S_DESC + 3, S_SOFF)
+    e('s_mov_b64 exec, s[%d:%d]', W_EX, W_EX + 1)
+    e('buffer_load_dword v%d, v%d, s[%d:%d], s%d offen', D_EDGE(r), OFF_EDGE(r), S_DESC, S_DESC + 3, S_SOFF)
+    e('s_mov_b64 exec, -1')
+    if r in (0, 5):
+        e('s_mov_b32 s%d, s%d', S_DESC + 2, S_PART_BYTES)
+
+
+def emit_wrw_advance(e, tag, role):
+    """the walk over the tiles: four tiles on, at the end of a tile row three pixel rows down, at the end of an image the other planes"""
+    e('s_add_u32 s%d, s%d, 64', S_SOFF, S_SOFF)
+    if role < 2:
+        e('s_mov_b32 s%d, s%d', W_EDGE_PREV, W_EDGE_CUR)       # of the chunk just requested: its transform runs one chunk later
+    e('s_sub_u32 s%d, s%d, 1', S_LEFT, S_LEFT)
+    e('s_cmp_lg_u32 s%d, 0', S_LEFT)
+    e('s_cbranch_scc1 %s', e.ref('SAMEROW_' + tag))
+    e('s_add_u32 s%d, s%d, s%d', S_SOFF, S_SOFF, S_STEP)
+    e('s_mov_b32 s%d, s%d', S_LEFT, S_CPP)
+    e('s_sub_u32 s%d, s%d, 1', W_ROWS, W_ROWS)
+    e('s_cmp_lg_u32 s%d, 0', W_ROWS)
+    e('s_cbranch_scc1 %s', e.ref('SAMEIMG_' + tag))
+    e('s_add_u32 s%d, s%d, s%d', S_SOFF, S_SOFF, W_IN_IMGSKIP)
+    e('s_mov_b32 s%d, s%d', W_ROWS, W_IN_TH)
+    e.label('SAMEIMG_' + tag)
+    if role < 2:
+        e('s_cmp_eq_u32 s%d, s%d', W_ROWS, W_IN_TH)
+        e('s_cselect_b32 s%d, s%d, s%d', W_TOPSZ, W_IN_ROWOFF, S_PART_BYTES)
+        e('s_cmp_eq_u32 s%d, 1', W_ROWS)
+        e('s_cselect_b32 s%d, s%d, s%d', W_BOTSZ, W_IN_ROWOFF, S_PART_BYTES)
+    e.label('SAMEROW_' + tag)
+    emit_wrw_edge_state(e, role)
+
+
+def emit_wrw_transform(e, role):
+    if 'noxform' in ABLATE:
+        return
+    if role < 2:
+        # the edge value's coefficient: the masked lanes' (v61: 0) where this chunk starts / ends a tile row
+        e('s_cmp_eq_u32 s%d, 1', W_EDGE_PREV)
+        e('s_cselect_b64 vcc, -1, 0')
+        e('v_cndmask_b32 v%d, %s, v%d, vcc', W_COEF, ('v%d' % W_FULL) if role == 0 else '1.0', IN_LANE16)     # (a literal and vcc are two constant-bus reads)
+        emit_transform_fwd(e, role, W_COEF)
+        return
+    # ---- role 2: Yt = A dY A^T of the lane's 4 x 4 output-gradient tile d[i][j] = v[16 + 4 i + j];  A[p][i] = point_p ^ i (inf: i = 3):
+    # 1-D: t(0) = d0, t(+-a) = (d0 + a^2 d2) +- a (d1 + a^2 d3), t(+-b) likewise, t(inf) = d3
+    D = lambda i, j: 16 + 4 * i + j
+    e('s_bitcmp1_b32 s%d, 0', W_IN_FLAGS)
+    e('s_cbranch_scc0 %s', e.ref('NOBIAS%d' % len(e.lines)))
+    skip = e.lines[-1].split()[-1]
+    for i in range(4):
+        for j in range(4):
+            e('v_add_f32 v%d, v%d, v%d', W_BSUM + j, W_BSUM + j, D(i, j))
+    e.lines.append(skip + ':')
+
+    def one_d(x, out_pm):
+        """x: four registers; out_pm: registers of t(+a), t(-a), t(+b), t(-b).  8 instructions."""
+        for (pt, (op, om)) in ((A_PT, out_pm[0:2]), (B_PT, out_pm[2:4])):
+            e('v_fmamk_f32 v%d, v%d, %s, v%d', W_E, x[2], lit(pt ** 2), x[0])
+            e('v_fmamk_f32 v%d, v%d, %s, v%d', W_O, x[3], lit(pt ** 2), x[1])
+            e('v_fmamk_f32 v%d, v%d, %s, v%d', op, W_O, lit(pt), W_E)
+            e('v_fmamk_f32 v%d, v%d, %s, v%d', om, W_O, lit(-pt), W_E)
+
+    for j in range(4):                                     # along i: columns of d
+        one_d([D(i, j) for i in range(4)], [W_T(p, j) for p in range(1, 5)])
+    OB = lambda ip: 16 if ip == 1 else 32                  # output quads of a row pair: v[32:43], v[16:27], v[32:43]
+    REG = lambda p, q: OB(p >> 1) + 4 * (q >> 1) + 2 * (q & 1) + (p & 1)
+    for ip in range(3):
+        for p in (2 * ip, 2 * ip + 1):                     # along j: row p of the half-transformed tile
+            y = [D(0, j) for j in range(4)] if p == 0 else [D(3, j) for j in range(4)] if p == 5 else [W_T(p, j) for j in range(4)]
+            one_d(y, [REG(p, q) for q in range(1, 5)])
+            e('v_mov_b32 v%d, v%d', REG(p, 0), y[0])
+            e('v_mov_b32 v%d, v%d', REG(p, 5), y[3])
+        for jp in range(3):
+            pos = position(2 * ip, 2 * jp)
+            assert pos % 4 == 0 and position(2 * ip + 1, 2 * jp) == pos + 1 and position(2 * ip, 2 * jp + 1) == pos + 2
+            e('ds_write_b128 v%d, %s offset:%d', V_W, quad(OB(ip) + 4 * jp), (pos >> 2) * KC * TM * 16)
+
+
+def emit_filter_transform(e, r):
+    """G^T m G of channel register r: m[i][j] = a[4 position(i, j) + r]  ->  v[9 r : 9 r + 8] = the 3 x 3 filter gradient, row-major.
+    G[point][tap] = point^tap / prod(point - others) (wino43::transform_weights); temporaries v[62:89].  Part of the loop statement (WRW):
+    handed to separate statements, the 144 accumulators were copied and spilled by the register allocator between them."""
+    a, b = A_PT, B_PT
+    n0, na, nb = a * a * b * b, 2 * a * a * (a * a - b * b), 2 * b * b * (b * b - a * a)
+    M = lambda i: 62 + i
+    S12, D12, S34, D34 = 68, 69, 70, 71
+    T = lambda t, j: 72 + 6 * t + j     # v[72:89]
+
+    def gt(x, out):
+        e('v_add_f32 v%d, v%d, v%d', S12, x[1], x[2])
+        e('v_sub_f32 v%d, v%d, v%d', D12, x[1], x[2])
+        e('v_add_f32 v%d, v%d, v%d', S34, x[3], x[4])
+        e('v_sub_f32 v%d, v%d, v%d', D34, x[3], x[4])
+        e('v_mul_f32 v%d, %s, v%d', out[0], litf(1 / n0), x[0])
+        e('v_mul_f32 v%d, %s, v%d', out[1], litf(a / na), D12)
+        e('v_fmamk_f32 v%d, v%d, %s, v%d', out[2], S12, litf(a * a / na), x[5])
+        e('v_fmac_f32 v%d, %s, v%d', out[0], litf(1 / na), S12)
+        e('v_fmac_f32 v%d, %s, v%d', out[1], litf(b / nb), D34)
+        e('v_fmac_f32 v%d, %s, v%d', out[2], litf(b * b / nb), S34)
+        e('v_fmac_f32 v%d, %s, v%d', out[0], litf(1 / nb), S34)
+
+    for j in range(6):
+        for i in range(6):
+            e('v_accvgpr_read_b32 v%d, a%d', M(i), 4 * position(i, j) + r)
+        gt([M(i) for i in range(6)], [T(t, j) for t in range(3)])
+    for t in range(3):
+        gt([T(t, j) for j in range(6)], [9 * r + 3 * t + c for c in range(3)])
+
 
 
 ABLATIONS = {1: {'noxform'}, 2: {'noloads'}, 3: {'nodma'}, 4: {'nobarrier'}, 5: {'nomfma'}, 6: {'noxform', 'noloads', 'nodma'},
@@ -469,7 +681,9 @@ def generate():
     e('s_and_b32 s%d, s%d, 0xffff', S_DESC + 1, S_PART(0)[1])
     e('s_mov_b32 s%d, s%d', S_DESC + 2, S_PART_BYTES)
     e('s_mov_b32 s%d, 0x00020000', S_DESC + 3)
-    if BLOCKS[0]:
+    if WRW[0]:
+        pass
+    elif BLOCKS[0]:
         e('s_mov_b32 s%d, 0', S_NEXT)                            # displacement of block (0, 0)
         e('s_mov_b32 s%d, s%d', S_NEXT + 2, S_PART(2)[0])       # blocks left in the block row: S
         e('s_mov_b32 s%d, s%d', S_MB_LEFT, S_CPP)               # the MFMA phase's own walk over the blocks (it runs a chunk behind the loads)
@@ -479,14 +693,25 @@ def generate():
     else:
         for i in range(3):
             e('s_mov_b64 s[%d:%d], s[%d:%d]', S_NEXT + 2 * i, S_NEXT + 2 * i + 1, S_PART(i + 1)[0], S_PART(i + 1)[1])
-    e('s_mov_b32 s%d, 0', S_SOFF)
-    e('s_mov_b32 s%d, s%d', S_LEFT, S_CPP)
+    if WRW[0]:
+        e('s_mov_b32 s%d, s%d', S_SOFF, W_IN_SOFF0)
+        e('s_mov_b32 s%d, s%d', S_LEFT, W_IN_LEFT0)
+    else:
+        e('s_mov_b32 s%d, 0', S_SOFF)
+        e('s_mov_b32 s%d, s%d', S_LEFT, S_CPP)
     e('s_mov_b32 s%d, s%d', S_REM, S_NCHUNKS)
-    e('s_mov_b64 s[%d:%d], s[%d:%d]', S_WP, S_WP + 1, S_ULO, S_UHI)
-    # DMA destinations: (wave & 3) * 1024 inside stage 0 / stage 1; the role word carries it: role | (wave & 3) << 8
-    e('s_lshr_b32 s%d, s%d, 8', S_T, S_ROLE)
-    e('s_lshl_b32 s%d, s%d, 10', S_DST_THIS, S_T)
-    e('s_add_u32 s%d, s%d, %d', S_DST_OTHER, S_DST_THIS, STAGE_B)
+    if WRW[0]:
+        e('s_mov_b32 s%d, s%d', W_ROWS, W_IN_ROWS0)
+        e('s_cmp_eq_u32 s%d, s%d', W_ROWS, W_IN_TH)
+        e('s_cselect_b32 s%d, s%d, s%d', W_TOPSZ, W_IN_ROWOFF, S_PART_BYTES)
+        e('s_cmp_eq_u32 s%d, 1', W_ROWS)
+        e('s_cselect_b32 s%d, s%d, s%d', W_BOTSZ, W_IN_ROWOFF, S_PART_BYTES)
+    else:
+        e('s_mov_b64 s[%d:%d], s[%d:%d]', S_WP, S_WP + 1, S_ULO, S_UHI)
+        # DMA destinations: (wave & 3) * 1024 inside stage 0 / stage 1; the role word carries it: role | (wave & 3) << 8
+        e('s_lshr_b32 s%d, s%d, 8', S_T, S_ROLE)
+        e('s_lshl_b32 s%d, s%d, 10', S_DST_THIS, S_T)
+        e('s_add_u32 s%d, s%d, %d', S_DST_OTHER, S_DST_THIS, STAGE_B)
     e('s_and_b32 s%d, s%d, 0xff', S_T, S_ROLE)
     e('s_cmp_eq_u32 s%d, 0', S_T)
     e('s_cbranch_scc1 %s', e.ref('ROLE_R0'))
@@ -496,6 +721,9 @@ def generate():
     for role in (0, 1, 2):
         emit_role(e, role)
     e.label('END')
+    if WRW[0]:
+        for r in range(4):                # G^T m G of the lane's four (k, c) pairs -> v[0:35]
+            emit_filter_transform(e, r)
     e('s_setprio 0')
     e('s_nop 15')
     e('s_nop 15')
@@ -566,6 +794,16 @@ def main():
         text.append('    "%s\\n" \\' % l)
     text.append('    ""')
     BLOCKS[0] = False
+    WRW[0] = True
+    text.append('// the weight-gradient form: roles 0 / 1 transform input patches of 32 channels x 4 tiles, role 2 output-gradient tiles of 64 channels')
+    text.append('#define TAI_W43_LOOP_ASM_WRW \\')
+    for l in generate():
+        text.append('    "%s\\n" \\' % l)
+    text.append('    ""')
+    WRW[0] = False
+    wv = ['"v%d"' % i for i in list(range(36, V_IN)) + list(range(V_IN + 16, V_LAST + 1)) if i != W_BSUM_OUT]
+    ws_ = ['"s%d"' % i for i in range(S_DESC, S_FLAGS + 1)]
+    text.append('#define TAI_W43_WRW_CLOBBERS %s' % ', '.join(wv + ['"a%d"' % i for i in range(144)] + ws_ + ['"vcc"', '"scc"', '"memory"']))
     text.append('#ifdef TAI_TIMING_VARIANTS   // timing experiments (wrong results by design): tools build only')
     for v, flags in sorted(ABLATIONS.items()):
         ABLATE.clear()

@@ -23,6 +23,9 @@ if os.environ.get('TAI_WINO43_AUTOGRAD') == '0':     # A/B: everything under aut
 if os.environ.get('TAI_DISC_S2D') == '0':           # A/B: the discriminator's 4x4 stride-2 layers on MIOpen (until round 5)
     from video_frame_inpainting_amd import sn_discriminator as _snd
     _snd._s2d_applies = lambda *a: False
+if os.environ.get('TAI_WRW_TILE'):                   # A/B: 2 = the F(2x2, 3x3)-domain weight-gradient kernel everywhere (rounds 2-5)
+    from video_frame_inpainting_amd import conv_ops as _cw
+    _cw.set_weight_gradient_tile(int(os.environ['TAI_WRW_TILE']))
 torch.manual_seed(0); np.random.seed(0)
 model = vfi.create_model('TAI_gray')
 env = create_training_environment(model, 1, '/tmp/ckpt_bench', 'x', 5, 5, 5, [128, 128], 1.0, 0.02, 1e-4, 0.5, 64, 3, 3, [0, 0], device=dev,

@@ -2,7 +2,7 @@
 without any source change: checked on the assembly of the very compile that produces the library (_native.build keeps
 it with -save-temps=obj) and refused if violated; tests/test_wino_isa.py runs the same checks and feeds them doctored text.
 
-wino43::conv3x3_gen (the F(4x4, 3x3) kernel): its chunk loop is one asm statement with fixed registers v0-v99 and
+wino43::conv3x3_gen and conv3x3_wrw_gen (the F(4x4, 3x3) kernel and its weight-gradient form): the chunk loop is one asm statement with fixed registers v0-v99 and
    a[0:143]; the compiler must give the kernel no scratch, no spill, and registers for two waves per SIMD (<= 256 in all): a
    spill would be vector-memory traffic the statement's own s_waitcnt vmcnt counting does not expect.
    (Round 4's compiler-scheduled forms of that kernel, whose asm loads depended on the compiler not touching their destination registers
@@ -43,6 +43,10 @@ def check(asm):
     gen = kernels(asm, '_ZN6wino4311conv3x3_gen')
     if not gen:
         bad.append('no wino43::conv3x3_gen kernel in the assembly')
+    wrw = kernels(asm, '_ZN6wino4315conv3x3_wrw_gen')       # the weight-gradient form of the same statement: the same rules
+    if not wrw:
+        bad.append('no wino43::conv3x3_wrw_gen kernel in the assembly')
+    gen.update(wrw)
     for name, (lines, desc) in gen.items():
         get = lambda key: int(re.search(r'\.amdhsa_%s\s+(\d+)' % key, desc).group(1))
         if get('private_segment_fixed_size') != 0 or any(re.search(r'\bscratch_(load|store)', l) for l in lines):

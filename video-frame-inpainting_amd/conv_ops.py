@@ -76,6 +76,17 @@ WINO43_MIN_WORKGROUPS = 150      # ... and where its 64-channel x 32-tile workgr
                                  # replayed configs[1] forward: 400: 51.11 ms, 256: 50.78, 150: 50.57, 100: 51.32, 64: 51.75 -- tools/w43_threshold_ab.py)
 
 
+def set_weight_gradient_tile(m):
+    """Transform domain of the 3x3 weight-gradient kernel (wino_weight_grad): 4 (default): F(4x4, 3x3) -- csrc/wino43_conv.hip.inc,
+    conv3x3_wrw_gen: the forward kernel's chunk loop with the tiles as the reduction, 1.78x fewer MFMAs, 1.15-1.5x faster per layer -- where
+    H % 4 == 0 and the input is a plain tensor; 2: F(2x2, 3x3) everywhere (csrc/wino_wrw.hip.inc, rounds 2-5).  Both sum in a fixed order.
+    Returns the previous value."""
+    prev = _native.lib().tai_conv3x3_wino_wrw_set_tile(m)
+    if prev < 0:
+        raise ValueError(m)
+    return prev
+
+
 def set_winograd_tile(m):
     """Output tile of the Winograd 3x3 convolutions: 4 (default since the end of round 4): F(4x4, 3x3), csrc/wino43_conv.hip.inc, on the
     layers with C >= 64 and K >= 64 (WINO43_MIN_CHANNELS; the layers marked by mark_outside_recurrence at any width) and enough workgroups

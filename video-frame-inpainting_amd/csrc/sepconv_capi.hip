@@ -830,10 +830,42 @@ static bool wrw_plan(int N, int C, int K, int H, int W, WrwPlan& p, int in_h = 0
     return true;
 }
 
+// The same gradient in the F(4x4, 3x3) domain (wino43::conv3x3_wrw_gen): blocks of 64 output x 32 input channels, chunks of four tiles
+// (16 pixels of a row), the run of chunks split over about one workgroup per CU; the slabs have the F(2x2) kernel's layout
+// [split][tap][Kpad][Cpad] (Cpad a multiple of 64) and go through the same wrw_reduce.
+static bool wrw43_plan(int N, int C, int K, int H, int W, WrwPlan& p, int in_h = 0, int in_w = 0, int in_oy = 0, int in_ox = 0) {
+    if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || H % 4 != 0 || W % 16 != 0) return false;
+    if (in_h <= 0) { in_h = H; in_w = W; }
+    // an input plane with a halo must hold the whole one-pixel frame of the output window (nothing is padded then)
+    if ((in_h != H || in_w != W) && (in_oy < 1 || in_ox < 1 || in_oy + H + 1 > in_h || in_ox + W + 1 > in_w)) return false;
+    if ((long long)N * C * in_h * in_w * 4 + (in_w + 1) * 4 >= (1LL << 31) || (long long)N * K * H * W * 4 >= (1LL << 31)) return false;
+    p.kblocks = (K + 63) / 64;
+    p.cblocks = (C + 31) / 32;
+    p.nchunks = (int)((long long)N * (H / 4) * (W / 16));
+    int want = 256 / (p.kblocks * p.cblocks);
+    if (want < 1) want = 1;
+    if (want > p.nchunks) want = p.nchunks;
+    p.chunks_per_split = (p.nchunks + want - 1) / want;
+    p.splits = (p.nchunks + p.chunks_per_split - 1) / p.chunks_per_split;
+    p.pair = 0;
+    return true;
+}
+
+static std::atomic<int> g_wrw_tile{4};              // 4 (default): the F(4x4, 3x3)-domain kernel where its shape rules allow, 2: F(2x2, 3x3) always
+int tai_conv3x3_wino_wrw_set_tile(int tile) {
+    if (tile != 2 && tile != 4) return -1;
+    return g_wrw_tile.exchange(tile, std::memory_order_relaxed);
+}
+
 long long tai_conv3x3_wino_wrw_workspace_floats(int N, int C, int K, int H, int W) {
-    WrwPlan p;
+    WrwPlan p, q;
     if (!wrw_plan(N, C, K, H, W, p)) return -1;
-    return (long long)p.splits * 9 * p.kblocks * 64 * p.cblocks * 64 + (long long)p.splits * p.kblocks * 64;     // taps, then bias partials
+    long long need = (long long)p.splits * 9 * p.kblocks * 64 * p.cblocks * 64 + (long long)p.splits * p.kblocks * 64;     // taps, then bias partials
+    if (wrw43_plan(N, C, K, H, W, q)) {              // (either kernel may serve the call: tai_conv3x3_wino_wrw_set_tile)
+        const long long n43 = (long long)q.splits * 9 * q.kblocks * 64 * ((C + 63) / 64 * 64) + (long long)q.splits * q.kblocks * 64;
+        if (n43 > need) need = n43;
+    }
+    return need;
 }
 
 static std::atomic<int> g_wrw_pair{1};              // 1: paired chunks (whole-line loads) when W % 32 == 0
@@ -852,6 +884,20 @@ static int wino_wrw_impl(const float* x, const float* dy, float* dw, float* dbia
     if (!wrw_plan(N, C, K, H, W, p, in_h, in_w))
         return fail(TAI_SEPCONV_EINVAL, "%s", "conv3x3_wino_wrw: needs even H, W % 16 == 0 and tensors below 2 GiB");
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    WrwPlan q;
+    if (g_wrw_tile.load(std::memory_order_relaxed) == 4 && !stamps && wrw43_plan(N, C, K, H, W, q, in_h, in_w, in_oy, in_ox)) {
+        const int Kpad = q.kblocks * 64, Cpad = (C + 63) / 64 * 64;
+        float* wsb43 = dbias ? workspace + (long long)q.splits * 9 * Kpad * Cpad : nullptr;
+        auto kern = wino43::conv3x3_wrw_gen;
+        if (int rc = allow_lds(kern, wino43::WRW_LDS_BYTES)) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(q.kblocks * q.cblocks * q.splits)), dim3(512), wino43::WRW_LDS_BYTES, stream, x, dy, workspace,
+                           wsb43, N, C, K, H, W, q.kblocks, q.cblocks, Kpad, Cpad, q.chunks_per_split, q.nchunks, in_h, in_w, in_oy, in_ox);
+        if (int rc = check_launch("conv3x3_wino43_wrw")) return rc;
+        const long long rows43 = 9LL * K * (Cpad / 64);
+        const int blocks43 = (int)(rows43 < 8192 ? (rows43 < q.kblocks ? q.kblocks : rows43) : 8192);
+        hipLaunchKernelGGL(wino::wrw::wrw_reduce, dim3(blocks43), dim3(256), 0, stream, workspace, dw, wsb43, dbias, K, C, Kpad, Cpad, q.splits);
+        return check_launch("conv3x3_wino43_wrw_reduce");
+    }
     const int grid = p.kblocks * p.cblocks * p.splits;
     float* wsb = dbias ? workspace + (long long)p.splits * 9 * p.kblocks * 64 * p.cblocks * 64 : nullptr;
 #define TAI_LAUNCH_WRW(D, P)                                                                                                   \
