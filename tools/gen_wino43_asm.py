@@ -86,6 +86,7 @@ def lit(x):
 
 
 C_A2B2, C_NSUM = A_PT ** 2 * B_PT ** 2, -(A_PT ** 2 + B_PT ** 2)       # rows 0 / inf: a^2 b^2 x0 - (a^2 + b^2) x2 + x4
+WRW_MID_ROLES = (2,)   # weight-gradient form: the roles that transform in the middle of the MFMA groups (see emit_role)
 WRW = [False]          # generate the weight-gradient form (see the WRW section below): roles 0 / 1 transform input patches of 32 channels x 4 tiles,
                        # role 2 transforms 64 x 4 output-gradient tiles (A dY A^T) instead of copying weights; the reduction runs over the tiles
 BLOCKS = [False]       # generate the displaced-read form (k x k filters as S x S blocks of 3 x 3 taps: see emit_patch_advance)
@@ -408,7 +409,10 @@ def emit_role(e, role):
     # ---- chunk loop.  Bodies per role: with a next chunk (its transform in the middle of the MFMA groups, its loads / DMA behind them)
     # and the plain one.  Behind the barrier every wave starts with MFMAs.
     e.label('LOOP_' + tag)
-    if not (patch and 'xform_first' in ABLATE):
+    # weight-gradient form: the two waves of a SIMD both transform; WRW_MID_ROLES do it between MFMA groups 3 and 4 instead of first, so that
+    # one wave of the pair has MFMAs to issue while the other waits for its loads and transforms
+    xf = 'xform_first' in ABLATE and not (WRW[0] and role in WRW_MID_ROLES)
+    if not (patch and xf):
         emit_read(e, 0, 0)
         emit_read(e, 1, 1)
     if patch:
@@ -417,7 +421,7 @@ def emit_role(e, role):
             emit_transform(e, role)                       # ... transformed into the other stage (6 LDS writes)
         e('s_cmp_lt_u32 s%d, 2', S_REM)                  # a next chunk?
         e('s_cbranch_scc1 %s', e.ref('PLAIN_' + tag))
-        if 'xform_first' in ABLATE:
+        if xf:
             # the transform in front of the MFMA groups (its six LDS writes sit behind the requests of groups 0 and 1: the counted wait of
             # group 0 -- everything but the two youngest requests -- covers them)
             transform_next()
@@ -433,15 +437,16 @@ def emit_role(e, role):
             e('s_cbranch_scc1 %s', e.ref('NOLOADS_' + tag))
             # the loads of the chunk after the next, one patch row behind each of groups 4 to 8 and the last behind group 8 as well: the
             # patch registers are free once the transform has read them
-            rows = {4: (0,), 5: (1,), 6: (2,), 7: (3,), 8: (4, 5)}
-            emit_mfma_phase(e, lambda g: [emit_patch_row_load(e, r) for r in rows.get(g, ())], transform_next, 6)
-            emit_patch_advance(e, tag + 'L')
+            rows = {4: (0,), 5: (1,), 6: (2,), 7: (3,), 8: (4, 5)} if load_rows(role) == 6 else {4: (0,), 5: (1,), 6: (2,), 7: (3,)}
+            nw = 9 if (WRW[0] and role == 2) else 6          # LDS writes of the transform
+            emit_mfma_phase(e, lambda g: [emit_patch_row_load(e, r, role) for r in rows.get(g, ())], transform_next, nw)
+            emit_patch_advance(e, tag + 'L', role)
             e('s_branch %s', e.ref('CHUNK_END_' + tag))
             e.label('NOLOADS_' + tag)
-            emit_mfma_phase(e, None, transform_next, 6)
+            emit_mfma_phase(e, None, transform_next, nw)
             e('s_branch %s', e.ref('CHUNK_END_' + tag))
         e.label('PLAIN_' + tag)
-        if 'xform_first' in ABLATE:
+        if xf:
             emit_read(e, 0, 0)
             emit_read(e, 1, 1)
             e.label('PLAIN_NOREAD_' + tag)
@@ -795,12 +800,15 @@ def main():
     text.append('    ""')
     BLOCKS[0] = False
     WRW[0] = True
+    ABLATE.update(f for f in os.environ.get('TAI_WRW_ABLATE', '').split(',') if f)      # timing experiments (wrong results), never committed output
     text.append('// the weight-gradient form: roles 0 / 1 transform input patches of 32 channels x 4 tiles, role 2 output-gradient tiles of 64 channels')
     text.append('#define TAI_W43_LOOP_ASM_WRW \\')
     for l in generate():
         text.append('    "%s\\n" \\' % l)
     text.append('    ""')
     WRW[0] = False
+    ABLATE.clear()
+    ABLATE.update(SCHEDULE)
     wv = ['"v%d"' % i for i in list(range(36, V_IN)) + list(range(V_IN + 16, V_LAST + 1)) if i != W_BSUM_OUT]
     ws_ = ['"s%d"' % i for i in range(S_DESC, S_FLAGS + 1)]
     text.append('#define TAI_W43_WRW_CLOBBERS %s' % ', '.join(wv + ['"a%d"' % i for i in range(144)] + ws_ + ['"vcc"', '"scc"', '"memory"']))

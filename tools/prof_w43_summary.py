@@ -6,6 +6,8 @@ root = sys.argv[1]
 
 
 def short(name):
+    if 'wino43' in name and 'conv3x3_wrw_gen' in name:
+        return 'wino43 weight grad'
     if 'wino43' in name and 'conv3x3_gen' in name:
         return 'wino43 generated'
     if 'wino43' in name and 'conv3x3<' in name:
