@@ -539,7 +539,7 @@ def secondary_configs(device, parity=True):
     return res
 
 
-_TRAIN_KERNEL_GROUPS = (('winograd weight gradient', ('wino::wrw',)), ('winograd forward / input gradient', ('wino::conv3x3', 'wino43::conv3x3')),
+_TRAIN_KERNEL_GROUPS = (('winograd weight gradient', ('wino::wrw', 'wino43::conv3x3_wrw')), ('winograd forward / input gradient', ('wino::conv3x3', 'wino43::conv3x3')),
                         ('sepconv forward', ('fwd::sepconv',)), ('sepconv backward', ('bwd::',)), ('spectral norm', ('snorm::',)),
                         ('MIOpen / rocBLAS', ('miopen', 'MIOpen', 'igemm', 'Cijk', 'gemm', 'naive_conv', 'SubTensor', 'batched_transpose', 'Igemm')),
                         ('other in-tree kernels', ('thin::', 'ups::', 'bact::', 'lstm::', 'pool::', 'wino::', 'wino43::')),

@@ -50,11 +50,14 @@ def _assert_matches_oracle(out, ref, GT, name='', min_levels=50, min_spread=0.05
     """Outputs within REL_TOL of the oracle relative to each key's own magnitude, AND the comparison is about something:
     the uint8 prediction spans many gray levels, PSNR vs ground truth differs between frames, and PSNR / SSIM vs ground
     truth agree between GPU and oracle (0.01 dB / 1e-4)."""
+    errs = {}
     for k in KEYS:
         scale = float(ref[k].abs().max())
         assert scale > 0.05, (name, k, scale)                 # a near-zero reference would make the check vacuous
         err = float((out[k].cpu() - ref[k]).abs().max())
+        errs[k] = err / scale
         assert err <= rel_tol * scale, (name, k, err, scale)
+    print('%s: max |gpu - oracle| / max |oracle|  %s  (bound %.0e)' % (name, '  '.join('%s %.2e' % kv for kv in errs.items()), rel_tol))      # pytest -s
     pred_gpu, pred_cpu = out['pred'].cpu().numpy(), ref['pred'].numpy()
     assert len(np.unique(metrics.to_uint8(pred_gpu))) > min_levels, name
     p_gpu, s_gpu, _ = metrics.compute_errors(pred_gpu, GT.numpy())

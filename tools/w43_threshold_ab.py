@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Same-box A/B of the configs[1] forward over conv_ops.WINO43_MIN_WORKGROUPS (below it a layer stays on F(2x2, 3x3)): one hipGraph per
-value, replayed alternately.  Usage: python tools/w43_threshold_ab.py [values ...]"""
+"""Same-box A/B of the configs[1] forward over conv_ops.WINO43_MIN_WORKGROUPS (below it a layer stays on F(2x2, 3x3)) or, with --channels,
+over conv_ops.WINO43_MIN_CHANNELS: one hipGraph per value, replayed alternately.
+Usage: python tools/w43_threshold_ab.py [--channels] [values ...]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +10,8 @@ import video_frame_inpainting_amd as vfi
 from video_frame_inpainting_amd import conv_ops, synthetic
 from video_frame_inpainting_amd.graph import GraphedForward
 
-values = [int(v) for v in sys.argv[1:]] or [400, 256, 150, 100, 64]
+KNOB = 'WINO43_MIN_CHANNELS' if '--channels' in sys.argv else 'WINO43_MIN_WORKGROUPS'
+values = [int(v) for v in sys.argv[1:] if v != '--channels'] or ([128, 64, 32, 16] if KNOB.endswith('CHANNELS') else [400, 256, 150, 100, 64])
 dev = torch.device('cuda:0')
 model = synthetic.seeded_init(vfi.create_model('TAI_gray'), 0).to(dev).eval()
 clips = synthetic.make_clips(32, 15, 1, 128, 128, synthetic.SEEDS['cfg2'])
@@ -18,7 +20,7 @@ graphs = {}
 with torch.no_grad():
     model(5, P, Fo)
     for v in values:
-        conv_ops.WINO43_MIN_WORKGROUPS = v
+        setattr(conv_ops, KNOB, v)
         model(5, P, Fo)
         graphs[v] = GraphedForward(model, 5, P, Fo, warmup=1)
     for rnd in range(2):
