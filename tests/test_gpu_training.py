@@ -559,5 +559,7 @@ def test_discriminator_layer_on_space_to_depth_planes_matches_the_direct_form(sh
     for name, a, o, r in zip(('y', 'gx', 'gw', 'gb'), got, old, (yd.detach(), xd.grad, wu.grad, bd.grad)):
         scale = float(r.abs().max())
         e_new, e_old = float((a.double() - r).abs().max()) / scale, float((o.double() - r).abs().max()) / scale
-        print('%s %s: in-tree %.2e  MIOpen %.2e of the maximum' % (shape, name, e_new, e_old))
+        # (the MIOpen route's gradients are scored here with the IN-TREE route's kink sides, so its own rounding flips count against it:
+        # only its y is comparable)
+        print('%s %s: in-tree %.2e of the maximum%s' % (shape, name, e_new, '  (MIOpen route: %.2e)' % e_old if name == 'y' else ''))
         assert e_new <= 2e-5, (name, e_new, e_old)
