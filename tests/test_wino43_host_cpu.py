@@ -41,3 +41,30 @@ def test_predict_option_exists():
     opt = TestOptions().parse(['--name', 'x', '--model_key', 'TAI_gray', '--K', '5', '--T', '5', '--F', '5', '--qual_result_root', '/tmp/q', '--winograd_tile', '4',
                               '--synthetic', '1'], allow_unknown=True, require_gpu=False)
     assert opt.winograd_tile == 4
+
+
+@pytest.mark.parametrize('C, K, H, W', [(3, 5, 16, 16), (4, 2, 8, 12), (1, 3, 4, 4)])
+def test_discriminator_layer_as_a_3x3_layer_on_space_to_depth_planes(C, K, H, W):
+    """The host side of the discriminator's in-tree route (sn_discriminator._s2d_weight / _s2d_weight_grad; SNDiscriminator.py:113-133): a
+    4x4, stride-2, padding-1 layer equals the 3x3, stride-1, padding-1 layer over F.pixel_unshuffle(x, 2) with the rearranged weight -- output,
+    input gradient (pixel_shuffle of the 3x3 layer's) and weight gradient (folded back) -- in float64, exactly up to summation order."""
+    import torch
+    import torch.nn.functional as F
+    from video_frame_inpainting_amd.sn_discriminator import _s2d_applies, _s2d_weight, _s2d_weight_grad
+    g = torch.Generator().manual_seed(C + K + H)
+    x = torch.randn(2, C, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(K, C, 4, 4, generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, w, None, 2, 1)
+    w3 = _s2d_weight(w)
+    assert w3.shape == (K, 4 * C, 3, 3) and int((w3 != 0).sum()) == K * C * 16          # 20 of the 36 slots per channel are structural zeros
+    assert float((y - F.conv2d(F.pixel_unshuffle(x, 2), w3, None, 1, 1)).abs().max()) < 1e-12
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    gw, = torch.autograd.grad(y, w, gy)
+    w3d = w3.detach().requires_grad_()
+    g3, = torch.autograd.grad(F.conv2d(F.pixel_unshuffle(x, 2), w3d, None, 1, 1), w3d, gy)
+    assert float((gw - _s2d_weight_grad(g3, C)).abs().max()) < 1e-12
+    xr = x.clone().requires_grad_()
+    gx, = torch.autograd.grad(F.conv2d(xr, w.detach(), None, 2, 1), xr, gy)
+    gxs = F.conv2d(gy, w3.detach().transpose(0, 1).flip(2, 3), None, 1, 1)
+    assert float((gx - F.pixel_shuffle(gxs, 2)).abs().max()) < 1e-12
+    assert not _s2d_applies(x, w, (2, 2), (1, 1))                                        # host tensors keep the reference's route
