@@ -800,7 +800,11 @@ def main():
     text.append('    ""')
     BLOCKS[0] = False
     WRW[0] = True
-    ABLATE.update(f for f in os.environ.get('TAI_WRW_ABLATE', '').split(',') if f)      # timing experiments (wrong results), never committed output
+    wrw_ablate = [f for f in os.environ.get('TAI_WRW_ABLATE', '').split(',') if f]      # timing experiments (wrong results): tools/wrw43_ablate.py
+    ABLATE.update(wrw_ablate)
+    if wrw_ablate:      # the kernel source refuses to compile such an output unless asked to (-DTAI_ALLOW_ABLATED): it must never reach the library
+        text.append('#define TAI_W43_WRW_ABLATED "%s"' % ' '.join(wrw_ablate))
+        print('WARNING: weight-gradient chunk loop generated WITHOUT %s: timing experiments only' % ', '.join(wrw_ablate))
     text.append('// the weight-gradient form: roles 0 / 1 transform input patches of 32 channels x 4 tiles, role 2 output-gradient tiles of 64 channels')
     text.append('#define TAI_W43_LOOP_ASM_WRW \\')
     for l in generate():

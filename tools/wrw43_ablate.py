@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """us per call of tai_conv3x3_wino_wrw through a library given by PATH (ctypes, no source-hash check): for the ablated builds of the
-weight-gradient kernel -- TAI_WRW_ABLATE=noloads|noxform|nobarrier python tools/gen_wino43_asm.py, hipcc -shared of csrc/sepconv_capi.hip to a
+weight-gradient kernel -- TAI_WRW_ABLATE=noloads|noxform|nobarrier python tools/gen_wino43_asm.py, hipcc -shared -DTAI_ALLOW_ABLATED of csrc/sepconv_capi.hip to a
 scratch path, then regenerate without the variable (results of an ablated library are wrong by design; profiles/r05_wrw43_ablation.txt).
 Usage: python tools/wrw43_ablate.py path/to/lib.so"""
 import ctypes, os, sys
