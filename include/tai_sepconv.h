@@ -259,6 +259,11 @@ int tai_conv3x3_wino43_forward_blocks(const float* x, int shift_k, const float* 
  * library was built with -DTAI_TIMING_VARIANTS (wrong results by design).  Returns the previous value, -1 on a value this build does not have
  * (round 4's compiler-scheduled forms 8 / 4 are no longer in the library). */
 int tai_conv3x3_wino43_set_waves(int waves);
+/* Workgroup placement of the F(4x4, 3x3) kernels (forward, blocks, weight gradient), process-wide: 1 (default) = aware of the chip's 8 XCDs
+ * (the hardware deals consecutive workgroups to them in turn, each with its own L2): an XCD gets one output-channel block and a contiguous
+ * run of tile blocks (forward) / whole splits (weight gradient); 0 = the plain dispatch order of rounds 4-5.  Same results; for A/B timing.
+ * Returns the previous value. */
+int tai_conv3x3_wino43_set_placement(int xcd_aware);
 /* ... with the input given as 1 to 4 equal channel parts (contiguous [N, C / nparts, H, W] tensors; C / nparts a multiple of 4): the
  * operands of a torch.cat along the channels that is never materialised (tai_conv3x3_wino_forward_parts' counterpart). */
 int tai_conv3x3_wino43_forward_parts(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C, int K,

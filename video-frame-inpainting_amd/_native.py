@@ -221,6 +221,8 @@ def lib():
     L.tai_conv3x3_wino_wrw_window.restype = I
     L.tai_conv3x3_wino_wrw_set_paired.argtypes = [I]
     L.tai_conv3x3_wino_wrw_set_paired.restype = I
+    L.tai_conv3x3_wino43_set_placement.argtypes = [I]
+    L.tai_conv3x3_wino43_set_placement.restype = I
     L.tai_conv3x3_wino_wrw_set_tile.argtypes = [I]
     L.tai_conv3x3_wino_wrw_set_tile.restype = I
     L.tai_window_scale_bias_lrelu.argtypes = [P, P, P, I, I, I, I, ctypes.c_float, V]

@@ -696,6 +696,11 @@ int tai_conv3x3_wino43_set_waves(int waves) {
     return g_wino43_waves.exchange(waves, std::memory_order_relaxed);
 }
 
+// Workgroup placement of the F(4x4, 3x3) kernels (forward and weight gradient): 1 (default) = aware of the 8 XCDs and their L2s (see
+// conv3x3_gen / conv3x3_wrw_gen), 0 = the dispatch order of rounds 4-5.  Same results either way; for A/B timing.
+static std::atomic<int> g_wino43_placement{1};
+int tai_conv3x3_wino43_set_placement(int xcd_aware) { return g_wino43_placement.exchange(xcd_aware ? 1 : 0, std::memory_order_relaxed); }
+
 static int wino43_forward_impl(const float* const* xs, int nparts, const float* U, const float* bias, float* y, int N, int C, int K, int H,
                                int W, int act, void* hip_stream, float* ypool = nullptr, const float* addx = nullptr, float* y2 = nullptr) {
     if (!xs || !xs[0] || !U || !bias || !y || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || nparts < 1 || nparts > 4)
@@ -719,12 +724,14 @@ static int wino43_forward_impl(const float* const* xs, int nparts, const float* 
     const long long tiles = (long long)N * (H / 4) * (W / 4);
     const long long tblocks = (tiles + wino43::TN - 1) / wino43::TN;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    wino43::Window plain_win{};
+    plain_win.dispatch_order = g_wino43_placement.load(std::memory_order_relaxed) ? 0 : 1;
 #define TAI_W43_LAUNCH_GEN(A, E)                                                                                                \
     {                                                                                                                           \
         auto kern = wino43::conv3x3_gen<A, E>;                                                                                  \
         if (int rc = allow_lds(kern, wino43::LDS_BYTES)) return rc;                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(512), wino43::LDS_BYTES, s, p[0], p[1], p[2], p[3],   \
-                           cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, ypool, addx, y2, wino43::Window{});        \
+                           cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, ypool, addx, y2, plain_win);               \
     }
 #ifdef TAI_TIMING_VARIANTS
 #define TAI_W43_LAUNCH_VAR(V)                                                                                                   \
@@ -732,7 +739,7 @@ static int wino43_forward_impl(const float* const* xs, int nparts, const float* 
         auto kern = wino43::conv3x3_gen<1, 0, V>;                                                                               \
         if (int rc = allow_lds(kern, wino43::LDS_BYTES)) return rc;                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)(tblocks * kblocks)), dim3(512), wino43::LDS_BYTES, s, p[0], p[1], p[2], p[3],   \
-                           cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, ypool, addx, y2, wino43::Window{});        \
+                           cpart, U, bias, y, N, C, K, H, W, Kpad, nchunks, kblocks, ypool, addx, y2, plain_win);               \
         return check_launch("conv3x3_wino43 (ablation)");                                                                       \
     }
     switch (g_wino43_waves.load(std::memory_order_relaxed)) {
@@ -794,7 +801,8 @@ int tai_conv3x3_wino43_forward_blocks(const float* x, int shift_k, const float* 
     const long long tiles = (long long)N * (H / 4) * (W / 4);
     const long long tblocks = (tiles + wino43::TN - 1) / wino43::TN;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    const wino43::Window win{in_h, in_w, in_oy, in_ox, S, ypool ? pool_h : 0, pool_w, pool_oy, pool_ox, 3 * S > shift_k ? 1 : 0};
+    const wino43::Window win{in_h, in_w, in_oy, in_ox, S, ypool ? pool_h : 0, pool_w, pool_oy, pool_ox, 3 * S > shift_k ? 1 : 0,
+                             g_wino43_placement.load(std::memory_order_relaxed) ? 0 : 1};
 #define TAI_W43_LAUNCH_BLOCKS(A, E)                                                                                             \
     {                                                                                                                           \
         auto kern = wino43::conv3x3_gen<A, E, 0, true>;                                                                         \
@@ -842,9 +850,20 @@ static bool wrw43_plan(int N, int C, int K, int H, int W, WrwPlan& p, int in_h =
     p.kblocks = (K + 63) / 64;
     p.cblocks = (C + 31) / 32;
     p.nchunks = (int)((long long)N * (H / 4) * (W / 16));
-    int want = 256 / (p.kblocks * p.cblocks);
-    if (want < 1) want = 1;
-    if (want > p.nchunks) want = p.nchunks;
+    // splits: one workgroup per CU where the blocks divide the 256 CUs; otherwise the count (up to 32, at least 16 chunks each) whose
+    // last round of workgroups is fullest -- 144 blocks (the 7x7 layer's stack: 36 x 4) as 1 split leave 112 CUs idle for the whole
+    // kernel, as 7 splits 4 rounds of 252 run in 0.57 of that time
+    const int blocks = p.kblocks * p.cblocks;
+    int want = 1;
+    double best = 1e30;
+    auto rounds_per_split = [&](int sp) { return (double)((blocks * sp + 255) / 256) / sp; };
+    for (int sp = 1; sp <= 32 && sp <= p.nchunks && (sp == 1 || p.nchunks / sp >= 16); ++sp) best = rounds_per_split(sp) < best ? rounds_per_split(sp) : best;
+    for (int sp = 1; sp <= 32; ++sp)                 // the smallest count within 3 % of the best (every split writes a slab and runs an epilogue)
+        if (rounds_per_split(sp) <= 1.03 * best) { want = sp; break; }
+    if (blocks * want < 256) {                       // fewer workgroups than CUs in one round: as many splits as fill it
+        want = 256 / blocks;
+        if (want > p.nchunks) want = p.nchunks;
+    }
     p.chunks_per_split = (p.nchunks + want - 1) / want;
     p.splits = (p.nchunks + p.chunks_per_split - 1) / p.chunks_per_split;
     p.pair = 0;
@@ -891,7 +910,8 @@ static int wino_wrw_impl(const float* x, const float* dy, float* dw, float* dbia
         auto kern = wino43::conv3x3_wrw_gen;
         if (int rc = allow_lds(kern, wino43::WRW_LDS_BYTES)) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)(q.kblocks * q.cblocks * q.splits)), dim3(512), wino43::WRW_LDS_BYTES, stream, x, dy, workspace,
-                           wsb43, N, C, K, H, W, q.kblocks, q.cblocks, Kpad, Cpad, q.chunks_per_split, q.nchunks, in_h, in_w, in_oy, in_ox);
+                           wsb43, N, C, K, H, W, q.kblocks, q.cblocks, Kpad, Cpad, q.chunks_per_split, q.nchunks, in_h, in_w, in_oy, in_ox,
+                           g_wino43_placement.load(std::memory_order_relaxed) ? 0 : 1);
         if (int rc = check_launch("conv3x3_wino43_wrw")) return rc;
         const long long rows43 = 9LL * K * (Cpad / 64);
         const int blocks43 = (int)(rows43 < 8192 ? (rows43 < q.kblocks ? q.kblocks : rows43) : 8192);
