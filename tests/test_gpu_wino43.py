@@ -303,3 +303,25 @@ def test_motion_enc_chain_on_the_4x4_tile_matches_the_2x2_tile(monkeypatch):
     for a, b in zip(outs[4], outs[2]):
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
     assert float((outs[4][0] - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+def test_workgroup_placement_changes_nothing_but_the_order():
+    """tai_conv3x3_wino43_set_placement: the XCD-aware mapping of workgroups to (tile block, channel block) / (split, c block, k block) is a
+    permutation of the plain dispatch order -- forward, displaced-read blocks and the weight gradient give the same bits under both, for
+    grids that are and are not multiples of 8 and for 1, 2, 3, 4, 8 and 16 channel blocks."""
+    from video_frame_inpainting_amd import _native, conv_ops
+    L = _native.lib()
+    assert L.tai_conv3x3_wino43_set_placement(1) == 1                      # the default
+    try:
+        for (N, C, K, H, W) in ((8, 64, 64, 32, 32), (8, 64, 128, 32, 32), (3, 32, 130, 16, 16), (8, 32, 256, 16, 16), (4, 16, 512, 16, 16),
+                                (2, 16, 1024, 16, 16), (5, 20, 64, 12, 20)):
+            x, w, b = _operands(N, C, K, H, W)
+            go = torch.randn(N, K, H, W, device='cuda')
+            res = {}
+            for v in (1, 0):
+                L.tai_conv3x3_wino43_set_placement(v)
+                res[v] = (_run([x], w, b, 'relu').clone(), conv_ops.wino_weight_grad(x, go) if W % 16 == 0 else None)
+            assert torch.equal(res[0][0], res[1][0]), (N, C, K, H, W)
+            assert res[0][1] is None or torch.equal(res[0][1], res[1][1]), (N, C, K, H, W)
+    finally:
+        L.tai_conv3x3_wino43_set_placement(1)
